@@ -1,0 +1,113 @@
+"""Decode-time head-sparse attention over the paged KV cache (MI355X HIP kernel).
+
+Mirror of the reference module `compactor_vllm/attention/sparse_decode_kernel.py`
+(wrapper :10-165, heuristic :169-192): same function names, argument order, defaults and
+assertions; the Triton stage-1 / stage-2 kernels are replaced by `cvllm_decode_attn`.
+"""
+from __future__ import annotations
+
+import functools
+import math
+
+import torch
+
+from .. import _lib
+
+# MI355X: 256 CUs.  The HIP kernel wants >= ~2 workgroups per CU; each workgroup streams a
+# contiguous run of rows of one (batch, kv-head).
+_TARGET_WORKGROUPS = 512
+_MIN_ROWS_PER_SPLIT = 256
+_MAX_INTERNAL_SPLITS = 128
+
+_workspaces: dict = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Persistent per-(device, stream) scratch so decode stays graph-capture safe (no allocation
+    inside the captured region after the first, un-captured, warm-up call)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def plan_internal_splits(n_bh: int, max_len_bound: int, key_split: int | None) -> int:
+    """Number of key splits the HIP kernel uses.  Depends only on host integers (batch, heads,
+    the page-table width bound, the caller's key_split hint) so the launch is capture safe."""
+    want = max(1, -(-_TARGET_WORKGROUPS // max(n_bh, 1)))
+    cap = max(1, max_len_bound // _MIN_ROWS_PER_SPLIT)
+    s = min(want, cap, _MAX_INTERNAL_SPLITS)
+    if key_split:
+        s = max(s, min(int(key_split), _MAX_INTERNAL_SPLITS))
+    return max(1, s)
+
+
+def head_sparse_decode_attention(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    seq_lens_bh: torch.Tensor,
+    global_page_table: torch.Tensor,
+    batch_mapping: torch.Tensor,
+    HKV: int,
+    PAGE_SIZE: int,
+    sm_scale: float = None,
+    key_split: int = None,
+):
+    """Same contract as the reference wrapper (sparse_decode_kernel.py:10-68).
+
+    q: [B, HQ, D] (or [B, HQ, 1, D]); k, v: global caches [CACHE_SIZE, D]; seq_lens_bh [B, HKV]
+    int32 (lengths including the current token); global_page_table [MAX_BATCHES, HKV, P];
+    batch_mapping [B].  Returns [B, HQ, D] in q.dtype.
+
+    Differences, all documented in DESIGN.md: `key_split` is a lower-bound hint — the HIP kernel
+    sub-splits further to fill 256 CUs (results equal up to fp32 rounding); with key_split=None no
+    host sync happens (the reference reads seq_lens_bh.max()); rows with L == 0 return zeros.
+    """
+    _lib.require_cuda(q, k, v, seq_lens_bh, global_page_table, batch_mapping)
+    if q.ndim != 3:
+        assert q.ndim == 4
+        B, HQ, S, D = q.shape
+        assert S == 1, "head_sparse_decode_attention only supports q_len=1"
+        q = q.squeeze(-2)
+    B, HQ, D = q.shape
+    assert PAGE_SIZE % 32 == 0, "PAGE_SIZE must be divisible by 32"
+    GROUP_M = HQ // HKV
+    assert GROUP_M * HKV == HQ, "HQ must be divisible by H_kv"
+    assert B <= 32767, "too many batches"
+    assert global_page_table.shape[1] == HKV
+    assert q.is_contiguous()
+    assert (D & (D - 1)) == 0, "D must be a power of 2"
+    assert k.is_contiguous() and v.is_contiguous() and k.shape[1] == D and v.shape[1] == D
+    assert global_page_table.is_contiguous()
+    n_lp = global_page_table.shape[-1]
+    sm_scale = 1 / math.sqrt(D) if sm_scale is None else sm_scale
+
+    seq_lens_bh = _lib.i32(seq_lens_bh)
+    batch_mapping = _lib.i32(batch_mapping)
+    page_table = _lib.i32(global_page_table)
+    n_splits = plan_internal_splits(B * HKV, n_lp * PAGE_SIZE, key_split)
+
+    L = _lib.lib()
+    out = torch.empty_like(q)
+    ws = None
+    ws_bytes = 0
+    if n_splits > 1:
+        ws_bytes = L.cvllm_decode_workspace_bytes(B, HQ, D, n_splits)
+        ws = _workspace(q.device, ws_bytes)
+    st = L.cvllm_decode_attn(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), seq_lens_bh.data_ptr(),
+        page_table.data_ptr(), batch_mapping.data_ptr(), _lib.ptr(ws), ws_bytes, B, HQ, HKV, D, PAGE_SIZE,
+        n_lp, float(sm_scale), n_splits, _lib.dtype_code(q.dtype), _lib.stream(),
+    )
+    _lib.check(st, "cvllm_decode_attn")
+    return out
+
+
+@functools.lru_cache(maxsize=128)
+def num_splits_heuristic(total_mblocks: int, max_seq_len: int, num_sms: int, max_splits: int) -> int:
+    """Reference heuristic (sparse_decode_kernel.py:169-192), evaluated by the C ABI's host
+    restatement so both sides agree bit for bit; kept because ModelRunner imports it."""
+    return int(_lib.lib().cvllm_num_splits(int(total_mblocks), int(max_seq_len), int(num_sms), int(max_splits)))

@@ -1,0 +1,249 @@
+// a9 — joint top-k selection + per-head page padding, without a global sort.
+//
+// Replaces cv/compression/common.py:171-243 (scores_to_retain_indices: pad + torch.topk full sort,
+// python loop with host syncs) and the rank-consuming logic of cv/kv_cache/store_kv_cache.py:9-78,
+// 178-248 (atomic scatter + serial per-head pad scan).
+//
+// Semantics: rank all (token, head) pairs of a sequence by (score desc, flat index asc);
+// keep ranks < retain_b; every head whose new length is not a page multiple also keeps its own next-ranked
+// tokens until the page is full / its tokens are exhausted / written >= ctx_len - L.  Because the joint
+// order restricted to one head IS that head's order, the final kept set of head h is simply the top
+//   t_h = c_h + pad_h     of head h's own scores,   c_h = #{kept pairs of head h in the joint top-retain}.
+// So:  kernel 1 (one workgroup per sequence): exact radix select of the retain-th largest joint key,
+//      count c_h, derive t_h;   kernel 2 (one workgroup per (sequence, head)): exact radix select of the
+//      t_h-th largest key of the head, then an ordered compaction (block scan) of the kept token indices.
+// Both are L2-resident passes over <= L*H floats; they run on the store stream under the prefill attention.
+#include "common.h"
+
+namespace cvllm {
+
+constexpr int SEL_T = 1024;  // threads per workgroup
+constexpr int SEL_W = SEL_T / 64;
+constexpr int SEL_MAXH = 64;
+
+__device__ __forceinline__ uint32_t order_key(float x) {
+  uint32_t u = __float_as_uint(x);
+  if (u == 0x80000000u) u = 0u;             // -0.0 == +0.0 under float comparison (torch.topk / sort semantics)
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN ranks above +inf, like torch.sort(descending)
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending uint order == ascending float order
+}
+
+// Exact selection of the r-th largest (1-based, 1 <= r <= n) ordered key among n strided floats.
+// Returns the key value v and `quota` = how many elements equal to v belong to the top r
+// (count(key > v) = r - quota).  All SEL_T threads must call; hist is LDS [256], s_state LDS [2].
+__device__ void radix_select_desc(const float* __restrict__ base, int stride, int n, int r, uint32_t* hist,
+                                  uint32_t* s_state, uint32_t& v_out, int& quota_out) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0;
+  int remaining = r;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += SEL_T) {
+      const int i = i0 + tid;
+      bool act = false;
+      uint32_t digit = 0;
+      if (i < n) {
+        const uint32_t k = order_key(base[(size_t)i * stride]);
+        act = pass == 0 || (k >> (shift + 8)) == prefix;
+        digit = (k >> shift) & 0xffu;
+      }
+      // wave-aggregated histogram: a few leader rounds soak up the heavy bins, the rest use LDS atomics
+#pragma unroll 1
+      for (int round = 0; round < 4; ++round) {
+        const unsigned long long am = __ballot(act);
+        if (am == 0ull) break;
+        const int leader = __ffsll((long long)am) - 1;
+        const uint32_t ld = __shfl((int)digit, leader, 64);
+        const unsigned long long mm = __ballot(act && digit == ld);
+        if ((tid & 63) == leader) atomicAdd(&hist[ld], (uint32_t)__popcll(mm));
+        if (digit == ld) act = false;
+      }
+      if (act) atomicAdd(&hist[digit], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // one wave walks the 256 bins from the top: 4 bins per lane, lane 0 owns the largest
+      const int lane = tid;
+      const int b0 = 255 - 4 * lane;
+      const uint32_t c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+      const uint32_t mine = c0 + c1 + c2 + c3;
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const uint32_t excl = incl - mine;  // elements in strictly larger bins than this lane's four
+      const uint32_t rem = (uint32_t)remaining;
+      if (excl < rem && rem <= incl) {
+        uint32_t acc = excl;
+        int d = b0;
+        if (acc + c0 >= rem) { d = b0; }
+        else { acc += c0; if (acc + c1 >= rem) { d = b0 - 1; }
+        else { acc += c1; if (acc + c2 >= rem) { d = b0 - 2; }
+        else { acc += c2; d = b0 - 3; } } }
+        s_state[0] = (uint32_t)d;
+        s_state[1] = rem - acc;  // remaining rank inside bin d
+      }
+    }
+    __syncthreads();
+    prefix = (prefix << 8) | s_state[0];
+    remaining = (int)s_state[1];
+    __syncthreads();
+  }
+  v_out = prefix;
+  quota_out = remaining;
+}
+
+// block-wide exclusive scan of a 0/1 flag over SEL_T threads; returns exclusive prefix, total via s_tot
+__device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_wsum, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wsum[wave] = __popcll(bal);
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SEL_W; ++w) {
+    const int c = s_wsum[w];
+    if (w < wave) woff += c;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  return woff + before;
+}
+
+// kernel 1: one workgroup per sequence -> target[b,h] = t_h (rows of head h to keep), new_lens
+__global__ __launch_bounds__(SEL_T) void select_joint_kernel(
+    const float* __restrict__ scores, const int* __restrict__ cu, const int* __restrict__ retain,
+    const int* __restrict__ bh_lens0, const int* __restrict__ bmap, int* __restrict__ target,
+    int* __restrict__ new_lens, int H, int PS, int pad, int reserved) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SEL_W];
+  __shared__ int s_cnt[SEL_MAXH];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  const bool skip = Lb <= 0 || bmap[b] == reserved;
+  if (skip) {
+    if (tid < H) {
+      target[b * H + tid] = 0;
+      new_lens[b * H + tid] = bh_lens0[b * H + tid];
+    }
+    return;
+  }
+  const int n = Lb * H;
+  int r = retain[b];
+  r = r < 0 ? 0 : (r > n ? n : r);
+  if (tid < H) s_cnt[tid] = 0;
+  __syncthreads();
+  const float* base = scores + (size_t)n0 * H;
+  if (r > 0) {
+    uint32_t v;
+    int quota;
+    radix_select_desc(base, 1, n, r, hist, s_state, v, quota);
+    // count kept pairs per head; ties at v are taken in ascending flat index (running tie counter)
+    const int stride = (SEL_T / H) * H;  // multiple of H: a thread always sees the same head
+    int local = 0;
+    int ties_before = 0;
+    for (int i0 = 0; i0 < n; i0 += stride) {
+      const int i = i0 + tid;
+      const bool in = tid < stride && i < n;
+      uint32_t k = 0;
+      if (in) k = order_key(base[i]);
+      const bool tie = in && k == v;
+      int tot;
+      const int tr = block_excl_scan_flag(tie, s_wsum, tot);
+      if (in && (k > v || (tie && ties_before + tr < quota))) ++local;
+      ties_before += tot;
+    }
+    if (local) atomicAdd(&s_cnt[tid % H], local);
+    __syncthreads();
+  }
+  if (tid < H) {
+    const int c = s_cnt[tid];
+    const int L0 = bh_lens0[b * H + tid];
+    const int L = L0 + c;
+    int take = c;
+    if (pad && (L % PS) != 0) {
+      const int need = PS - L % PS;
+      int extra = min(need, min(Lb - L, Lb - c));  // store_kv_cache.py:209-220
+      take += extra > 0 ? extra : 0;
+    }
+    target[b * H + tid] = take;
+    new_lens[b * H + tid] = L0 + take;
+  }
+}
+
+// kernel 2: one workgroup per (sequence, head): top-t_h of the head's column -> ordered token list
+__global__ __launch_bounds__(SEL_T) void select_head_kernel(const float* __restrict__ scores,
+                                                            const int* __restrict__ cu,
+                                                            const int* __restrict__ target,
+                                                            int* __restrict__ kept_idx, int H, int max_seqlen) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SEL_W];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  const int t = target[b * H + h];
+  if (t <= 0 || Lb <= 0) return;
+  const float* base = scores + (size_t)n0 * H + h;
+  int* list = kept_idx + ((size_t)b * H + h) * max_seqlen;
+  if (t >= Lb) {
+    for (int i = tid; i < Lb; i += SEL_T) list[i] = i;
+    return;
+  }
+  uint32_t v;
+  int quota;
+  radix_select_desc(base, H, Lb, t, hist, s_state, v, quota);
+  int ties_before = 0, kept_before = 0;
+  for (int i0 = 0; i0 < Lb; i0 += SEL_T) {
+    const int i = i0 + tid;
+    const bool in = i < Lb;
+    uint32_t k = 0;
+    if (in) k = order_key(base[(size_t)i * H]);
+    const bool tie = in && k == v;
+    int tot_t, tot_k;
+    const int tr = block_excl_scan_flag(tie, s_wsum, tot_t);
+    const bool keep = in && (k > v || (tie && ties_before + tr < quota));
+    const int slot = block_excl_scan_flag(keep, s_wsum, tot_k);
+    if (keep) list[kept_before + slot] = i;
+    ties_before += tot_t;
+    kept_before += tot_k;
+  }
+}
+
+}  // namespace cvllm
+
+using namespace cvllm;
+
+extern "C" size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen) {
+  (void)max_seqlen;
+  if (B <= 0 || H <= 0) return 0;
+  return (size_t)B * H * sizeof(int32_t);
+}
+
+extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_k, const int32_t* retain,
+                                 const int32_t* bh_lens0, const int32_t* batch_mapping, int32_t* kept_idx,
+                                 int32_t* new_lens, int B, int H, int max_seqlen, int page_size, int pad_to_page,
+                                 int reserved_batch, void* workspace, size_t workspace_bytes,
+                                 cvllm_stream_t stream) {
+  if (!scores || !cu_seqlens_k || !retain || !bh_lens0 || !batch_mapping || !kept_idx || !new_lens)
+    return CVLLM_ERR_ARG;
+  if (B <= 0 || H <= 0 || max_seqlen <= 0 || page_size <= 0) return CVLLM_ERR_ARG;
+  if (H > SEL_MAXH || (SEL_T % H) != 0 && H > SEL_T) return CVLLM_ERR_SHAPE;
+  if (!workspace || workspace_bytes < cvllm_select_workspace_bytes(B, H, max_seqlen)) return CVLLM_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* target = (int*)workspace;
+  hipLaunchKernelGGL(select_joint_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, retain, bh_lens0,
+                     batch_mapping, target, new_lens, H, page_size, pad_to_page, reserved_batch);
+  hipLaunchKernelGGL(select_head_kernel, dim3(B * H), dim3(SEL_T), 0, st, scores, cu_seqlens_k, target, kept_idx, H,
+                     max_seqlen);
+  return check_launch();
+}

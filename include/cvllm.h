@@ -1,0 +1,190 @@
+/*
+ * cvllm.h — C ABI of the MI355X-native hot path of compactor-vllm (libcvllm_hip.so).
+ *
+ * One entry point per row of SURVEY.md §8(a).  Every function is `extern "C"`, takes raw DEVICE
+ * pointers, plain ints / strides (in ELEMENTS) and the HIP stream to enqueue on, never
+ * synchronises the device, allocates nothing, and returns an int status (0 = ok, negative =
+ * which precondition failed; see cvllm_error_string).  Entry points whose grid depends only on
+ * their integer arguments (decode attention, decode store) are HIP-graph-capture safe.
+ *
+ * The reference is pure Python/Triton (no FFI of its own); the "reference interface" each
+ * function replaces is therefore the Python wrapper + @triton.jit kernel cited next to it
+ * (paths relative to /root/reference/src/compactor_vllm/).  The Python host side that reproduces
+ * those wrappers' signatures lives in compactor-vllm_amd/compactor_vllm_amd/ and binds this
+ * library with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * dtype codes: 0 = float16, 1 = bfloat16 (K/V/Q element type).  Scores are float32 unless noted.
+ * All index tensors are int32 and contiguous.  Head dim D in {64,128,256}; GQA group
+ * G = HQ/HKV in {1,2,4,8}.
+ */
+#ifndef CVLLM_H
+#define CVLLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cvllm_stream_t; /* hipStream_t */
+
+#define CVLLM_F16 0
+#define CVLLM_BF16 1
+
+#define CVLLM_OK 0
+#define CVLLM_ERR_ARG (-1)         /* null pointer / non-positive size */
+#define CVLLM_ERR_SHAPE (-2)       /* unsupported D, G, page size or dtype */
+#define CVLLM_ERR_WORKSPACE (-3)   /* workspace too small */
+#define CVLLM_ERR_LAUNCH (-4)      /* hipLaunch error (hipGetLastError) */
+
+int cvllm_version(void);
+const char* cvllm_error_string(int status);
+
+/* ---- a2: decode attention ---------------------------------------------------------------
+ * replaces attention/sparse_decode_kernel.py:10-165 head_sparse_decode_attention,
+ *          :246-388 _varkv_stage1_groupM, :391-435 _varkv_stage2_reduce.
+ * q[B,HQ,D] contiguous; k_cache/v_cache [cache_rows,D]; seq_lens_bh[B,HKV] (lengths INCLUDING the
+ * current token); page_table[*,HKV,n_logical_pages_max]; batch_mapping[B]; out[B,HQ,D].
+ * n_splits is the number of key splits the kernel uses internally (>=1); workspace holds the
+ * fp32 partials.  Rows with L==0 produce zeros (reference: uninitialised, quirk Q6).        */
+size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits);
+int cvllm_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
+                      const int32_t* seq_lens_bh, const int32_t* page_table,
+                      const int32_t* batch_mapping, void* workspace, size_t workspace_bytes,
+                      int B, int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
+                      float sm_scale, int n_splits, int dtype, cvllm_stream_t stream);
+
+/* replaces attention/sparse_decode_kernel.py:169-192 num_splits_heuristic (host, same results) */
+int cvllm_num_splits(int total_mblocks, int max_seq_len, int num_sms, int max_splits);
+
+/* ---- a4: decode cache append --------------------------------------------------------------
+ * replaces kv_cache/store_kv_cache.py:419-466 decode_store_kv + :374-416 kernel.
+ * key/value [B,HKV,D] with element strides (s_b,s_h), last dim contiguous.  Appends one row per
+ * (b,h) at bh_lens[b,h] and increments it; rows with batch_mapping[b]==reserved_batch skipped. */
+int cvllm_store_decode_kv(const void* key, const void* value, int64_t sk_b, int64_t sk_h,
+                          int64_t sv_b, int64_t sv_h, const int32_t* batch_mapping,
+                          int32_t* bh_lens, const int32_t* page_table, void* k_cache,
+                          void* v_cache, int B, int HKV, int D, int page_size,
+                          int n_logical_pages_max, int reserved_batch, int dtype,
+                          cvllm_stream_t stream);
+
+/* ---- a3: uncompressed prefill cache write -------------------------------------------------
+ * replaces kv_cache/store_kv_cache.py:322-371 prefill_store_all_kv + :251-319 kernel.
+ * new_keys/new_values [N,HKV,D] with element strides (s_n,s_h).  Row (t,h) of sequence b goes
+ * to logical position bh_lens[b,h]+t; afterwards bh_lens[b,:] += len_b (done on device).   */
+int cvllm_store_all_kv(const void* new_keys, const void* new_values, int64_t sk_n, int64_t sk_h,
+                       int64_t sv_n, int64_t sv_h, const int32_t* cu_seqlens_k,
+                       const int32_t* batch_mapping, int32_t* bh_lens,
+                       const int32_t* page_table, void* k_cache, void* v_cache, int B,
+                       int total_tokens, int HKV, int D, int page_size,
+                       int n_logical_pages_max, int dtype, cvllm_stream_t stream);
+
+/* ---- a1: prefill attention ------------------------------------------------------------------
+ * replaces attention/sparse_varlen_kernel.py:11-197 causal_sparse_varlen_with_cache + :277-519.
+ * q[N,HQ,D] (stride sq_n, heads contiguous), k/v [N,HKV,D] with strides (s_n,s_h);
+ * seq_lens_bh[B,HKV] = cached prefix lengths BEFORE this step; out[N,HQ,D] contiguous.       */
+int cvllm_prefill_attn(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n,
+                       int64_t sk_h, int64_t sv_n, int64_t sv_h, const void* k_cache,
+                       const void* v_cache, void* out, const int32_t* seq_lens_bh,
+                       const int32_t* page_table, const int32_t* batch_mapping,
+                       const int32_t* cu_seqlens_q, int B, int total_tokens, int max_seqlen_q,
+                       int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
+                       float sm_scale, int dtype, cvllm_stream_t stream);
+
+/* ---- a6: segmented z-score -------------------------------------------------------------------
+ * replaces compression/compactor.py:224-269 _zscore_per_batch_epilogue_no_window.
+ * x[N,H] in place; score_dtype 0/1 = f16/bf16, 2 = f32; cu[n_segments+1] int32 row offsets.
+ * Optional fused epilogue (compactor.py:586-598): x = z(x) + blend*accum (accum_dtype as
+ * score_dtype, may be NULL), then rows [first,last) protected ranges <- +inf when
+ * prot_first/prot_last (int32 [n_segments]) are given.  Python-slice semantics of the
+ * reference's fills (quirk Q9) are reproduced by the host wrapper, which passes explicit
+ * [lo,hi) row ranges: prot_ranges int32 [n_ranges,2], may be NULL.                         */
+int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
+                          const void* accum, int accum_dtype, float blend,
+                          const int32_t* prot_ranges, int n_ranges, int total_rows,
+                          cvllm_stream_t stream);
+
+/* ---- a7: Compactor post-RoPE chunked non-causal attention mass -------------------------------
+ * replaces compression/compactor.py:338-486 _non_causal_attn_kernel (+ wrapper :489-580).
+ * mass[N,HKV] f32 (overwritten): column sums of row-softmax(q k^T * sm_scale) inside each
+ * chunk of `chunk_size` tokens of one sequence, plus the reference's padded-row term.        */
+int cvllm_chunk_attn_mass(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                          float* mass, const int32_t* cu_seqlens, int B, int total_tokens,
+                          int max_seqlen, int HQ, int HKV, int D, int chunk_size, float sm_scale,
+                          int dtype, cvllm_stream_t stream);
+
+/* ---- a5: Compactor pre-RoPE leverage scores ----------------------------------------------------
+ * replaces compression/compactor.py:113-221 approximate_leverage_scores (matmul + SVD path).
+ * key_states[N,HKV,D] (strides s_n,s_h), PHI[D,k] row-major same dtype, chunk_cu[n_chunks+1]
+ * int32 row offsets of the chunks (host-built exactly like split_into_chunks :62-110),
+ * scores[N,HKV] f32 out: x_i^T (Xc^T Xc + reg I)^-1 x_i.  Chunks longer than `max_chunk_rows`
+ * are rejected (CVLLM_ERR_SHAPE).                                                              */
+int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_t s_h, const void* phi,
+                          float* scores, const int32_t* chunk_cu, int n_chunks, int total_tokens,
+                          int HKV, int D, int sketch_dim, float regularizer, int dtype,
+                          void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
+size_t cvllm_leverage_workspace_bytes(int n_chunks, int HKV, int sketch_dim);
+
+/* ---- a8: SnapKV window scores -------------------------------------------------------------------
+ * replaces compression/snapkv.py:332-448 query_aware_key_scores + :39-157 + :160-276.
+ * scores[Nk,HKV] f32 out; window w (<=32*?); 5-tap trailing mean clipped at 128-key tiles
+ * (pinned); last w keys <- +inf; sequences with L<=w are all +inf.                 */
+int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                        float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                        int B, int HQ, int HKV, int D, int w, float sm_scale, int pool,
+                        int dtype, void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
+size_t cvllm_snapkv_workspace_bytes(int B, int HQ, int w, int max_seqlen_k);
+
+/* ---- a9: joint top-k selection ------------------------------------------------------------------
+ * replaces compression/common.py:171-243 scores_to_retain_indices (torch.topk full sort) and the
+ * rank-consuming half of kv_cache/store_kv_cache.py:9-78,178-248.
+ * scores[N,H] f32; per sequence keep the retain[b] largest (score desc, flat index asc), then
+ * pad every head up to a page boundary with its next-best tokens (pad_to_page).  Outputs:
+ * kept_idx[B,H,max_seqlen] int32 = LOCAL token indices of the retained rows of every (b,h) in
+ * ascending token order (first new_lens-bh_lens0 entries valid), new_lens[B,H] = bh_lens0 + kept
+ * count (bh_lens0 itself untouched).  Sequences with batch_mapping[b]==reserved_batch keep
+ * nothing.  retain[b] is clamped to L_b*H.                                                      */
+size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen);
+int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_k, const int32_t* retain,
+                      const int32_t* bh_lens0, const int32_t* batch_mapping, int32_t* kept_idx,
+                      int32_t* new_lens, int B, int H, int max_seqlen, int page_size,
+                      int pad_to_page, int reserved_batch, void* workspace,
+                      size_t workspace_bytes, cvllm_stream_t stream);
+
+/* ---- a10: compaction -----------------------------------------------------------------------------
+ * replaces kv_cache/store_kv_cache.py:81-175 prefill_store_topk_kv (scatter + pad kernels).
+ * Copies the kept rows of every (b,h) to logical slots bh_lens0[b,h].. in TOKEN order
+ * (deterministic; the reference is atomics-ordered and its test compares multisets).
+ * kept_idx / new_lens are the outputs of cvllm_select_topk.                                   */
+int cvllm_compact_store(const void* new_keys, const void* new_vals, int64_t sk_n, int64_t sk_h,
+                        int64_t sv_n, int64_t sv_h, const int32_t* kept_idx,
+                        const int32_t* new_lens, const int32_t* cu_seqlens_k,
+                        const int32_t* bh_lens0, const int32_t* page_table,
+                        const int32_t* batch_mapping, void* k_cache, void* v_cache, int B, int H,
+                        int D, int max_seqlen, int page_size, int n_logical_pages_max, int dtype,
+                        cvllm_stream_t stream);
+
+/* ranked-list variant with the reference's own argument list (indices_topk int32 [B,MAX_SEL]
+ * GLOBAL flat indices): store_kv_cache.py:81-248.  bh_lens updated in place.                 */
+int cvllm_store_topk_ranked(const void* new_keys, const void* new_vals, int64_t sk_n, int64_t sk_h,
+                            int64_t sv_n, int64_t sv_h, const int32_t* indices_topk,
+                            const int32_t* num_tokens_to_retain, const int32_t* page_table,
+                            const int32_t* batch_mapping, int32_t* bh_lens, void* k_cache,
+                            void* v_cache, const int32_t* cu_seqlens_k, int B, int H, int D,
+                            int max_sel, int page_size, int n_logical_pages_max,
+                            int pad_to_page, int reserved_batch, int dtype,
+                            cvllm_stream_t stream);
+
+/* full ranking for API parity with scores_to_retain_indices: out int64 [B, k_eff] global flat
+ * indices, (score desc, flat index asc); padded entries of shorter sequences follow in index
+ * order exactly as a stable sort of the reference's -inf padded matrix would give.          */
+size_t cvllm_rank_workspace_bytes(int B, int H, int max_seqlen);
+int cvllm_rank_indices(const float* scores, const int32_t* cu_seqlens_k, int64_t* out, int B,
+                       int H, int max_seqlen, int k_eff, void* workspace,
+                       size_t workspace_bytes, cvllm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVLLM_H */

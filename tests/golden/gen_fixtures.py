@@ -1,0 +1,316 @@
+"""Generate the committed golden vectors by RUNNING THE UPSTREAM REFERENCE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 TRITON_INTERPRET=1 python tests/golden/gen_fixtures.py
+
+Every case stores the exact inputs and the reference's outputs (tests/golden/<case>.npz) and,
+while generating, checks oracle/ref_cpu.py against the reference so the oracle is pinned at the
+moment the vectors are made.  The vectors are data only: no reference source travels.
+"""
+import math
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+import _ref_loader  # noqa: E402
+
+R = _ref_loader.load()
+
+import torch  # noqa: E402
+
+from golden_io import save_case  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def mk_paged(B, HKV, D, PS, lens_bh, dtype, seed, extra_pages=3, bmax_extra=1):
+    """Random paged cache: shuffled page table, batch_mapping != arange (rows >= 1), cache rows of
+    valid positions filled with N(0,1), everything else NaN-free garbage (0.5)."""
+    g = torch.Generator().manual_seed(seed)
+    P = max(1, int(max(-(-int(x) // PS) for x in lens_bh.flatten().tolist())))
+    Bmax = B + bmax_extra
+    n_pages = (Bmax + 1) * HKV * P + extra_pages
+    perm = torch.randperm(n_pages, generator=g)[: (Bmax + 1) * HKV * P]
+    page_table = perm.view(Bmax + 1, HKV, P).to(torch.int32).contiguous()
+    bm = (torch.randperm(Bmax, generator=g)[:B] + 1).to(torch.int32)
+    k_cache = torch.full((n_pages * PS, D), 0.5, dtype=dtype)
+    v_cache = torch.full((n_pages * PS, D), -0.5, dtype=dtype)
+    for b in range(B):
+        for h in range(HKV):
+            L = int(lens_bh[b, h])
+            rows = O.cache_rows(page_table[int(bm[b]), h], L, PS)
+            k_cache[rows] = torch.randn(L, D, generator=g).to(dtype)
+            v_cache[rows] = torch.randn(L, D, generator=g).to(dtype)
+    return k_cache, v_cache, page_table, bm, P
+
+
+def maxdiff(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------ a1
+def gen_prefill():
+    cases = [
+        # name, dtype, B, HQ, HKV, D, PS, cache lens (per b or 'var'), append lens
+        ("prefill_f16_nocache", torch.float16, 2, 8, 2, 128, 128, [0, 0], [70, 13]),
+        ("prefill_f16_varhead", torch.float16, 3, 8, 2, 128, 128, "var300", [1, 2, 200]),
+        ("prefill_bf16_varhead", torch.bfloat16, 2, 8, 2, 128, 128, "var300", [13, 130]),
+        ("prefill_f16_ps256_hq32", torch.float16, 2, 32, 8, 128, 256, "var300", [5, 66]),
+        ("prefill_f16_d64", torch.float16, 2, 4, 4, 64, 128, "var140", [1, 90]),
+    ]
+    for name, dtype, B, HQ, HKV, D, PS, cl, al in cases:
+        g = torch.Generator().manual_seed(sum(name.encode()) % 10000)
+        if isinstance(cl, str):
+            mx = int(cl[3:])
+            lens = torch.randint(0, mx + 1, (B, HKV), generator=g, dtype=torch.int32)
+            lens[0, 0] = 0
+            lens[-1, -1] = mx
+            if B > 1:
+                lens[1, 0] = PS  # exactly one page
+        else:
+            lens = torch.tensor(cl, dtype=torch.int32)[:, None].repeat(1, HKV)
+        kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=11)
+        cu = torch.tensor([0] + list(torch.tensor(al).cumsum(0).tolist()), dtype=torch.int32)
+        N = int(cu[-1])
+        q = torch.randn(N, HQ, D, generator=g).to(dtype)
+        # k and v as strided views of a fused qkv buffer, like the model's qkv.split (llama3.py:96-100)
+        qkv = torch.randn(N, (HQ + 2 * HKV) * D, generator=g).to(dtype)
+        k = qkv[:, HQ * D : (HQ + HKV) * D].view(N, HKV, D)
+        v = qkv[:, (HQ + HKV) * D :].view(N, HKV, D)
+        scale = 1.0 / math.sqrt(D)
+        ref = R.pk.causal_sparse_varlen_with_cache(
+            q, k, v, kc, vc, lens, pt, bm, cu, max(al), int(lens.max()), HKV, PS, scale
+        )
+        mine = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale)
+        print(f"{name}: oracle vs reference max|d| = {maxdiff(ref, mine):.3e}")
+        save_case(name, q=q, qkv=qkv, k_cache=kc, v_cache=vc, seq_lens_bh=lens, page_table=pt,
+                  batch_mapping=bm, cu_seqlens_q=cu, HQ=HQ, HKV=HKV, D=D, PAGE_SIZE=PS,
+                  sm_scale=scale, out=ref)
+
+
+# ------------------------------------------------------------------------------------------ a2
+def gen_decode():
+    cases = [
+        ("decode_f16_small", torch.float16, 3, 8, 2, 128, 128, [1, 2, 70], 1),
+        ("decode_f16_var_split3", torch.float16, 3, 8, 2, 128, 128, "var1000", 3),
+        ("decode_bf16_var_split2", torch.bfloat16, 2, 32, 8, 128, 128, "var400", 2),
+        ("decode_f16_ps256", torch.float16, 2, 8, 2, 128, 256, "var600", 1),
+        ("decode_f16_d64", torch.float16, 2, 8, 4, 64, 128, "var300", 2),
+    ]
+    for name, dtype, B, HQ, HKV, D, PS, cl, split in cases:
+        g = torch.Generator().manual_seed(sum(name.encode()) % 10000)
+        if isinstance(cl, str):
+            mx = int(cl[3:])
+            lens = torch.randint(1, mx + 1, (B, HKV), generator=g, dtype=torch.int32)
+            lens[0, 0] = 1
+            lens[-1, -1] = mx
+            if B > 1:
+                lens[1, 0] = PS
+        else:
+            lens = torch.tensor(cl, dtype=torch.int32)[:, None].repeat(1, HKV)
+        kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=23)
+        q = torch.randn(B, HQ, D, generator=g).to(dtype)
+        scale = 1.0 / math.sqrt(D)
+        ref = R.dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, scale, key_split=split)
+        mine = O.decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, scale)
+        print(f"{name}: oracle vs reference max|d| = {maxdiff(ref, mine):.3e}")
+        save_case(name, q=q, k_cache=kc, v_cache=vc, seq_lens_bh=lens, page_table=pt, batch_mapping=bm,
+                  HQ=HQ, HKV=HKV, D=D, PAGE_SIZE=PS, sm_scale=scale, key_split=split, out=ref)
+
+
+# ------------------------------------------------------------------------------------- a3 / a4
+def gen_stores():
+    for name, dtype, B, HKV, D, PS, al in [
+        ("storeall_f16", torch.float16, 3, 2, 64, 128, [10, 300, 70]),
+        ("storeall_bf16_hkv8", torch.bfloat16, 2, 8, 128, 128, [130, 17]),
+    ]:
+        g = torch.Generator().manual_seed(5)
+        lens0 = torch.randint(0, 200, (B, HKV), generator=g, dtype=torch.int32)
+        total = lens0 + torch.tensor(al, dtype=torch.int32)[:, None]
+        kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, total, dtype, seed=31)
+        cu = torch.tensor([0] + torch.tensor(al).cumsum(0).tolist(), dtype=torch.int32)
+        N = int(cu[-1])
+        HQ = 2 * HKV
+        qkv = torch.randn(N, (HQ + 2 * HKV) * D, generator=g).to(dtype)
+        k = qkv[:, HQ * D : (HQ + HKV) * D].view(N, HKV, D)
+        v = qkv[:, (HQ + HKV) * D :].view(N, HKV, D)
+        kc_ref, vc_ref, l_ref = kc.clone(), vc.clone(), lens0.clone()
+        R.st.prefill_store_all_kv(new_keys=k, new_values=v, cu_seqlens_k=cu, max_seqlen_k=max(al),
+                                  k_cache=kc_ref, v_cache=vc_ref, page_table=pt, bh_lens=l_ref,
+                                  batch_mapping=bm, PAGE_SIZE=PS)
+        kc_o, vc_o, l_o = kc.clone(), vc.clone(), lens0.clone()
+        O.store_all_kv(k, v, cu, kc_o, vc_o, pt, l_o, bm, PS)
+        ok = torch.equal(kc_o, kc_ref) and torch.equal(vc_o, vc_ref) and torch.equal(l_o, l_ref)
+        print(f"{name}: oracle == reference: {ok}")
+        assert ok
+        save_case(name, qkv=qkv, HQ=HQ, HKV=HKV, D=D, PAGE_SIZE=PS, cu_seqlens_k=cu, k_cache0=kc, v_cache0=vc,
+                  page_table=pt, batch_mapping=bm, bh_lens0=lens0, k_cache=kc_ref, v_cache=vc_ref, bh_lens=l_ref)
+
+    for name, dtype, B, HKV, D, PS in [
+        ("decodestore_f16", torch.float16, 4, 2, 64, 128),
+        ("decodestore_bf16", torch.bfloat16, 3, 8, 128, 128),
+    ]:
+        g = torch.Generator().manual_seed(6)
+        lens0 = torch.randint(0, 300, (B, HKV), generator=g, dtype=torch.int32)
+        lens0[0, 0] = 0
+        lens0[1, 1] = PS - 1
+        lens0[2, 0] = PS
+        kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens0 + 1, dtype, seed=37)
+        bm[B - 1] = 0  # RESERVED_BATCH padding row: must be skipped (store_kv_cache.py:395-397)
+        key = torch.randn(B, HKV, D, generator=g).to(dtype)
+        val = torch.randn(B, HKV, D, generator=g).to(dtype)
+        kc_ref, vc_ref, l_ref = kc.clone(), vc.clone(), lens0.clone()
+        R.st.decode_store_kv(key=key, value=val, batch_mapping=bm, bh_lens=l_ref, page_table=pt,
+                             k_cache=kc_ref, v_cache=vc_ref, PAGE_SIZE=PS)
+        kc_o, vc_o, l_o = kc.clone(), vc.clone(), lens0.clone()
+        O.decode_store_kv(key, val, bm, l_o, pt, kc_o, vc_o, PS)
+        ok = torch.equal(kc_o, kc_ref) and torch.equal(vc_o, vc_ref) and torch.equal(l_o, l_ref)
+        print(f"{name}: oracle == reference: {ok}")
+        assert ok
+        save_case(name, key=key, value=val, HKV=HKV, D=D, PAGE_SIZE=PS, k_cache0=kc, v_cache0=vc, page_table=pt,
+                  batch_mapping=bm, bh_lens0=lens0, k_cache=kc_ref, v_cache=vc_ref, bh_lens=l_ref)
+
+
+# ------------------------------------------------------------------------------------ a9 + a10
+def kept_from_cache(kc, new_keys, cu, pt, bm, lens_final, lens0, PS):
+    """Recover the retained token set of every (b,h) from the cache contents (rows are unique)."""
+    B, H = lens_final.shape
+    flat, offs = [], [0]
+    for b in range(B):
+        s, e = int(cu[b]), int(cu[b + 1])
+        for h in range(H):
+            L0, L1 = int(lens0[b, h]), int(lens_final[b, h])
+            rows = O.cache_rows(pt[int(bm[b]), h], L1, PS)[L0:]
+            toks = []
+            src = new_keys[s:e, h].float()
+            for r in rows.tolist():
+                m = (src == kc[r].float()[None, :]).all(-1).nonzero().flatten().tolist()
+                assert len(m) == 1, (b, h, r, m)
+                toks.append(m[0])
+            flat.extend(sorted(toks))
+            offs.append(len(flat))
+    return torch.tensor(flat, dtype=torch.int32), torch.tensor(offs, dtype=torch.int32)
+
+
+def gen_select():
+    cases = [
+        # name, B, HKV, D, PS, lens, ratios, first, last, pad
+        ("select_hkv8_pad", 3, 8, 32, 128, [300, 517, 70], [0.5, 0.25, 0.1], 16, 8, True),
+        ("select_hkv2_pad", 2, 2, 32, 128, [1300, 30], [0.1, 0.5], 4, 4, True),
+        ("select_hkv8_nopad", 2, 8, 64, 128, [300, 140], [0.25, 0.5], 16, 16, False),
+        ("select_short_q2", 2, 8, 32, 128, [50, 200], [1.0, 0.5], 16, 64, True),
+    ]
+    for name, B, H, D, PS, lens, ratios, first, last, pad in cases:
+        g = torch.Generator().manual_seed(77)
+        dtype = torch.float16
+        cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+        N = int(cu[-1])
+        scores = torch.randn(N, H, generator=g)
+        for b in range(B):  # protected tokens = +inf, as the scoring stage produces them
+            s, L = int(cu[b]), lens[b]
+            if L <= first + last:
+                continue  # all-protected sequences would be one big tie: order undefined upstream
+            scores[s : s + first] = float("inf")
+            scores[s + L - last : s + L] = float("inf")
+        retain = torch.tensor([O.retain_count(r, L, first, last, H) for r, L in zip(ratios, lens)],
+                              dtype=torch.int32)
+        lens0 = torch.zeros(B, H, dtype=torch.int32)
+        full = torch.tensor(lens, dtype=torch.int32)[:, None].repeat(1, H)
+        kc, vc, pt, bm, P = mk_paged(B, H, D, PS, full, dtype, seed=41)
+        keys = torch.randn(N, H, D, generator=g).to(dtype)
+        vals = torch.randn(N, H, D, generator=g).to(dtype)
+        kc_ref, vc_ref, l_ref = kc.clone(), vc.clone(), lens0.clone()
+        idx = R.cm.scores_to_retain_indices(scores, cu, max(lens), max(lens) * H, H)
+        R.st.prefill_store_topk_kv(new_keys=keys, new_vals=vals, indices_topk=idx, num_tokens_to_retain=retain,
+                                   page_table=pt, batch_mapping=bm, bh_lens=l_ref, k_cache=kc_ref, v_cache=vc_ref,
+                                   PAGE_SIZE=PS, PAD_TO_PAGE_SIZE=pad, cu_seqlens_k=cu)
+        kept_flat, kept_offs = kept_from_cache(kc_ref, keys, cu, pt, bm, l_ref, lens0, PS)
+        kept_o, l_o = O.retained_sets(scores, cu, retain, lens0, bm, PS, pad)
+        flat_o = [t for b in range(B) for h in range(H) for t in sorted(kept_o[b][h])]
+        ok = torch.equal(l_o, l_ref) and flat_o == kept_flat.tolist()
+        print(f"{name}: retain={retain.tolist()} final lens row0={l_ref[0].tolist()} oracle==reference: {ok}")
+        assert ok
+        save_case(name, scores=scores, cu_seqlens_k=cu, retain=retain, keys=keys, vals=vals, HKV=H, D=D, PAGE_SIZE=PS,
+                  pad=int(pad), page_table=pt, batch_mapping=bm, k_cache0=kc, v_cache0=vc, bh_lens0=lens0,
+                  bh_lens=l_ref, kept_flat=kept_flat, kept_offs=kept_offs, ref_indices=idx)
+
+
+# --------------------------------------------------------------------------- a5 / a6 / a7 / a8
+def gen_scoring():
+    # a5: leverage scores
+    for name, dtype, lens, chunk, H, D in [
+        ("leverage_f32_chunk512", torch.float32, [257, 127, 1300], 512, 2, 128),
+        ("leverage_f32_whole", torch.float32, [257, 127, 600], -1, 2, 128),
+        ("leverage_bf16_chunk512", torch.bfloat16, [600, 1100], 512, 4, 128),
+        ("leverage_f16_chunk128", torch.float16, [300, 128], 128, 2, 64),
+    ]:
+        g = torch.Generator().manual_seed(3)
+        N = sum(lens)
+        # keys with a low-rank + noise structure so leverage scores are informative
+        base = torch.randn(N, H, 16, generator=g) @ torch.randn(16, D, generator=g) * 0.3
+        k = (base + torch.randn(N, H, D, generator=g)).to(dtype)
+        PHI = (torch.randn(D, 48, generator=g) / math.sqrt(48)).to(dtype)
+        for norm in (False, True):
+            ref = R.cp.approximate_leverage_scores(k.clone(), lens, PHI, normalize=norm, chunk_size=chunk)
+            mine = O.leverage_scores(k, lens, PHI, normalize=norm, chunk_size=chunk)
+            print(f"{name} normalize={norm}: oracle vs reference max|d| = {maxdiff(ref, mine):.3e} "
+                  f"(|ref| max {ref.float().abs().max():.3f})")
+            save_case(f"{name}_norm{int(norm)}", k=k, PHI=PHI, context_lens=lens, chunk_size=chunk,
+                      normalize=int(norm), out=ref)
+
+    # a7: Compactor post-RoPE scores (full wrapper: mass, z-score per sequence, blend, protected)
+    for name, dtype, lens, HQ, HKV, D, first, last in [
+        ("chunkattn_f16", torch.float16, [257, 100, 600], 8, 2, 128, 16, 64),
+        ("chunkattn_bf16", torch.bfloat16, [130, 64], 16, 4, 128, 4, 8),
+        ("chunkattn_f16_d64", torch.float16, [200], 4, 4, 64, 16, 64),
+    ]:
+        g = torch.Generator().manual_seed(9)
+        N = sum(lens)
+        cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+        # 0.3-scaled so that sm_scale=1.0 logits are not a pure arg-max (still peaky, like real data)
+        q = (torch.randn(N, HQ, D, generator=g) * 0.3).to(dtype)
+        k = (torch.randn(N, HKV, D, generator=g) * 0.3).to(dtype)
+        v = torch.zeros(N, HKV, D, dtype=dtype)
+        pre = torch.randn(N, HKV, generator=g).to(dtype)
+        B = len(lens)
+        raw = R.cp.non_causal_attn_scores(q, k, v, cu, max(lens), chunk_size=128, sm_scale=1.0, normalize=False)
+        ref = R.cp.non_causal_attn_scores(q, k, v, cu, max(lens), chunk_size=128, sm_scale=1.0, normalize=True,
+                                          accum_scores=pre, context_lens=lens,
+                                          protected_first_tokens=[first] * B, protected_last_tokens=[last] * B,
+                                          accum_blending=0.5)
+        raw_o = O.chunk_attn_mass(q, k, cu, 128, 1.0)
+        mine = O.compactor_post_scores(q, k, cu, lens, pre, [first] * B, [last] * B)
+        fin = torch.isfinite(ref)
+        assert torch.equal(fin, torch.isfinite(mine))
+        print(f"{name}: mass max|d| = {maxdiff(raw, raw_o):.3e}; final max|d| = {maxdiff(ref[fin], mine[fin]):.3e}")
+        save_case(name, q=q, k=k, pre=pre, cu_seqlens=cu, context_lens=lens, first=first, last=last,
+                  HQ=HQ, HKV=HKV, D=D, mass=raw, out=ref)
+
+    # a8: SnapKV
+    for name, dtype, lens, HQ, HKV, D in [
+        ("snapkv_f16", torch.float16, [257, 100, 600], 8, 2, 128),
+        ("snapkv_bf16", torch.bfloat16, [300, 40], 16, 4, 128),
+    ]:
+        g = torch.Generator().manual_seed(10)
+        N = sum(lens)
+        cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+        q = torch.randn(N, HQ, D, generator=g).to(dtype)
+        k = torch.randn(N, HKV, D, generator=g).to(dtype)
+        ref = R.sk.query_aware_key_scores(q, k, cu, cu, w=32)
+        mine = O.snapkv_scores(q, k, cu, cu, 32)
+        fin = torch.isfinite(ref)
+        assert torch.equal(fin, torch.isfinite(mine))
+        print(f"{name}: oracle vs reference max|d| = {maxdiff(ref[fin], mine[fin]):.3e}")
+        save_case(name, q=q, k=k, cu_seqlens=cu, w=32, HQ=HQ, HKV=HKV, D=D, out=ref)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring"]
+    for w in which:
+        {"prefill": gen_prefill, "decode": gen_decode, "stores": gen_stores, "select": gen_select,
+         "scoring": gen_scoring}[w]()

@@ -1,0 +1,78 @@
+"""Kernel micro-benchmarks on one MI355X (HIP-event timed on the launch stream).
+
+    python tools/microbench.py decode [--L 16384] [--B 1] [--splits 0]
+"""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "compactor-vllm_amd"))
+
+import torch
+
+
+def time_fn(fn, iters=50, warmup=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def build_cache(B, HKV, D, PS, L, dtype, dev, layers=1, seed=0):
+    """`layers` independent caches so consecutive launches do not re-hit the 256 MiB Infinity Cache."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    P = -(-L // PS)
+    n_pages = (B + 1) * HKV * P
+    caches = []
+    for _ in range(layers):
+        kc = torch.randn(n_pages * PS, D, device=dev, dtype=dtype)
+        vc = torch.randn(n_pages * PS, D, device=dev, dtype=dtype)
+        caches.append((kc, vc))
+    pt = torch.randperm(n_pages, generator=g).view(B + 1, HKV, P).to(torch.int32).to(dev)
+    bm = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
+    lens = torch.full((B, HKV), L, dtype=torch.int32, device=dev)
+    return caches, pt, bm, lens
+
+
+def bench_decode(args):
+    import compactor_vllm_amd.attention.sparse_decode_kernel as dk
+
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16
+    B, HQ, HKV, D, PS, L = args.B, 32, 8, 128, 128, args.L
+    layers = max(1, min(32, int(600e6 // (2 * B * HKV * L * D * 2)) + 1))
+    caches, pt, bm, lens = build_cache(B, HKV, D, PS, L, dtype, dev, layers)
+    q = torch.randn(B, HQ, D, device=dev, dtype=dtype)
+    splits_list = [args.splits] if args.splits else [1, 4, 8, 16, 32, 48, 64, 96, 128]
+    bytes_alg = 2 * D * 2 * B * HKV * L + 2 * B * HQ * D * 2
+    for S in splits_list:
+        dk.plan_internal_splits = lambda n_bh, bound, ks, S=S: S
+        i = [0]
+
+        def fn():
+            kc, vc = caches[i[0] % layers]
+            i[0] += 1
+            dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS)
+
+        us = time_fn(fn)
+        print(f"decode B={B} L={L} splits={S:3d} layers={layers}: {us:8.2f} us/launch(+merge)  "
+              f"{bytes_alg / us / 1e6:7.3f} TB/s algorithmic", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what")
+    ap.add_argument("--L", type=int, default=16384)
+    ap.add_argument("--B", type=int, default=1)
+    ap.add_argument("--splits", type=int, default=0)
+    a = ap.parse_args()
+    {"decode": bench_decode}[a.what](a)
