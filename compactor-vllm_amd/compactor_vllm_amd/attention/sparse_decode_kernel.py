@@ -13,9 +13,10 @@ import torch
 
 from .. import _lib
 
-# MI355X: 256 CUs.  The HIP kernel wants >= ~2 workgroups per CU; each workgroup streams a
-# contiguous run of rows of one (batch, kv-head).
-_TARGET_WORKGROUPS = 512
+# MI355X: 256 CUs.  The ring kernel keeps ~128 KiB of LDS per workgroup, i.e. one workgroup per CU, and a CU
+# streams at most ~24 GB/s, so the plan is one workgroup per CU; each streams a contiguous run of rows of
+# one (batch, kv-head).
+_TARGET_WORKGROUPS = 256
 _MIN_ROWS_PER_SPLIT = 256
 _MAX_INTERNAL_SPLITS = 128
 

@@ -19,7 +19,6 @@
 namespace cvllm {
 
 constexpr int DEC_NW = 4;        // waves per workgroup
-constexpr int DEC_NL = 4;        // row-loads per unit per lane (K and V each)
 constexpr int DEC_PGCACHE = 512; // page ids cached in LDS per split
 
 template <int LPR>
@@ -34,8 +33,8 @@ __device__ __forceinline__ float group_allreduce_sum(float v) {
   return v;
 }
 
-template <typename T, int D, int G, bool DIRECT>
-__global__ __launch_bounds__(DEC_NW * 64) void decode_stage1_kernel(
+template <typename T, int D, int G, bool DIRECT, int DEC_NL, int MINW>
+__global__ __launch_bounds__(DEC_NW * 64, MINW) void decode_stage1_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
     const int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
@@ -247,59 +246,455 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_stage1_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Stage 1, LDS-ring form (the default).  A single CU sustains only ~24 GB/s of HBM loads, so reaching the
+// chip rate needs every CU busy with >= ~64 KiB in flight for the whole launch.  Registers cannot hold
+// that, LDS can: each wave owns a private ring of R unit slots in LDS and fills it with
+// global_load_lds_dwordx4 (LDS-DMA: lane l's 16 B land at slot + 16*l, the same coalesced row image),
+// keeps R-1 units in flight behind a COUNTED s_waitcnt vmcnt, and pulls the landed unit into registers
+// with ds_read_b128.  Rings are wave-private: no barrier in the loop.  The ds_reads and waits are inline
+// asm because hipcc otherwise drains vmcnt(0) before any LDS read while an LDS-DMA is pending.
+// Page ids of the split live in VGPRs (lane i holds page i) and are fetched with v_readlane: the loop has
+// no other memory instruction.
+template <int N>
+struct VmWait;
+#define CVLLM_VMWAIT(N)                                                             \
+  template <>                                                                       \
+  struct VmWait<N> {                                                                \
+    static __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); } \
+  };
+CVLLM_VMWAIT(0) CVLLM_VMWAIT(4) CVLLM_VMWAIT(8) CVLLM_VMWAIT(12) CVLLM_VMWAIT(16) CVLLM_VMWAIT(24)
+CVLLM_VMWAIT(32) CVLLM_VMWAIT(36) CVLLM_VMWAIT(48) CVLLM_VMWAIT(56) CVLLM_VMWAIT(20) CVLLM_VMWAIT(28)
+CVLLM_VMWAIT(40)
+
+constexpr int DEC_PGREGS = 4;  // page ids cached in registers: 4 x 64 pages per split
+
+template <typename T, int D, int G, bool DIRECT, int NW, int NL, int R, bool NT, bool DBG_NOCOMPUTE = false>
+__global__ __launch_bounds__(NW * 64) void decode_stage1_ring_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
+    const int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
+    int HKV, int PS, int NLP, int S, float scale) {
+  constexpr int LPR = D / 8;
+  constexpr int RPL = 64 / LPR;
+  constexpr int UR = RPL * NL;
+  constexpr int ROUND = UR * NW;
+  constexpr int UNIT_BYTES = 2 * NL * 1024;  // K loads then V loads
+  constexpr int P = R - 1;                   // units in flight ahead of the one being reduced
+  static_assert(2 * NL * P <= 60, "vmcnt is a 6-bit counter");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [NW][R][UNIT_BYTES] rings | s_acc[NW][G][D] f32 | s_m[NW][G] | s_l[NW][G]
+  float* s_acc = reinterpret_cast<float*>(smem + NW * R * UNIT_BYTES);
+  float* s_m = s_acc + NW * G * D;
+  float* s_l = s_m + NW * G;
+
+  const int bid = blockIdx.x;
+  const int s = bid % S;
+  const int bh = bid / S;
+  const int h = bh % HKV;
+  const int b = bh / HKV;
+  const int HQ = HKV * G;
+  const int L = seq_lens[bh];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c = lane / LPR;
+  const int dl = lane % LPR;
+
+  int per = (L + S - 1) / S;
+  per = (per + ROUND - 1) / ROUND * ROUND;
+  const int start = s * per;
+  const int end = min(start + per, L);
+
+  if (start >= end) {
+    if (DIRECT) {
+      for (int i = tid; i < G * D; i += NW * 64) out[((size_t)b * HQ + h * G) * D + i] = 0;
+    } else if (tid < G) {
+      part_lse[(size_t)(b * S + s) * HQ + h * G + tid] = -INFINITY;
+    }
+    return;
+  }
+
+  const int bt = bmap[b];
+  const int* pt = page_table + ((size_t)bt * HKV + h) * NLP;
+  const int lp0 = start / PS;
+  const int nlp = (end - 1) / PS - lp0 + 1;  // <= 64 * DEC_PGREGS (checked on the host)
+  int pgreg[DEC_PGREGS];
+#pragma unroll
+  for (int j = 0; j < DEC_PGREGS; ++j) {
+    const int i = lane + 64 * j;
+    pgreg[j] = i < nlp ? pt[lp0 + i] : 0;
+  }
+
+  uint4 qf[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+    qf[g] = *reinterpret_cast<const uint4*>(q + ((size_t)b * HQ + h * G + g) * D + dl * 8);
+
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = -INFINITY;
+    l[g] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[g][d] = 0.f;
+  }
+
+  // Retire every ordinary load before the first LDS-DMA and hide the registers' origin from hipcc: it would
+  // otherwise wait vmcnt(0) at each later use of q / page ids, draining the ring every iteration.
+#pragma unroll
+  for (int j = 0; j < DEC_PGREGS; ++j) asm volatile("" : "+v"(pgreg[j]));
+#pragma unroll
+  for (int g = 0; g < G; ++g) asm volatile("" : "+v"(qf[g].x), "+v"(qf[g].y), "+v"(qf[g].z), "+v"(qf[g].w));
+
+  const int nunits = (end - start + UR - 1) / UR;
+  const int njw = nunits > wave ? (nunits - wave + NW - 1) / NW : 0;  // units owned by this wave
+  char* ring = smem + wave * (R * UNIT_BYTES);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  const uint32_t lane_off = lane * 16;
+
+  auto page_of = [&](int lpi) {
+    int pg = __builtin_amdgcn_readlane(pgreg[0], lpi & 63);
+#pragma unroll
+    for (int j = 1; j < DEC_PGREGS; ++j)
+      if ((lpi >> 6) == j) pg = __builtin_amdgcn_readlane(pgreg[j], lpi & 63);
+    return pg;
+  };
+
+  auto issue = [&](int j) {  // wave-local unit j -> ring slot j % R
+    const int row0 = start + (wave + j * NW) * UR;
+    const int pg = page_of(row0 / PS - lp0);
+    const size_t base = ((size_t)pg * PS + (row0 % PS) + c) * D + dl * 8;
+    char* slot = ring + (j % R) * UNIT_BYTES;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const uint16_t* kp = kc + base + (size_t)i * RPL * D;
+      const uint16_t* vp = vc + base + (size_t)i * RPL * D;
+      constexpr int AUX = NT ? 2 : 0;  // nt: once-read stream, do not keep in L2
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
+                                       (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
+                                       (__attribute__((address_space(3))) void*)(slot + (NL + i) * 1024), 16, 0, AUX);
+    }
+  };
+
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+    if (j < njw) issue(j);
+
+  for (int j = 0; j < njw; ++j) {
+    if (j + P < njw) {
+      issue(j + P);
+      VmWait<2 * NL * P>::wait();
+    } else {
+      VmWait<0>::wait();  // tail: drain
+    }
+    uint4 kk[NL], vv[NL];
+    {
+      const uint32_t a = ring_lds + (j % R) * UNIT_BYTES + lane_off;
+      if constexpr (NL == 4) {
+        asm volatile(
+            "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
+            "ds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\t"
+            "ds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(kk[0]), "=&v"(kk[1]), "=&v"(kk[2]), "=&v"(kk[3]), "=&v"(vv[0]), "=&v"(vv[1]), "=&v"(vv[2]),
+              "=&v"(vv[3])
+            : "v"(a)
+            : "memory");
+      } else {
+        static_assert(NL == 2, "NL must be 2 or 4");
+        asm volatile(
+            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+            "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(kk[0]), "=&v"(kk[1]), "=&v"(vv[0]), "=&v"(vv[1])
+            : "v"(a)
+            : "memory");
+      }
+    }
+    const int rbase = start + (wave + j * NW) * UR + c;
+    if (DBG_NOCOMPUTE) {  // timing experiment: stream only (results are garbage)
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc[0][i & 7] += __uint_as_float((kk[i].x ^ vv[i].w) & 0x3fffffffu);
+      continue;
+    }
+    float sc[NL][G];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float a = dot2<T>(kk[i].x, qf[g].x, 0.f);
+        a = dot2<T>(kk[i].y, qf[g].y, a);
+        a = dot2<T>(kk[i].z, qf[g].z, a);
+        a = dot2<T>(kk[i].w, qf[g].w, a);
+        sc[i][g] = a;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool valid = (rbase + i * RPL) < end;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float r = group_allreduce_sum<LPR>(sc[i][g]);
+        sc[i][g] = valid ? r * scale : -INFINITY;
+      }
+    }
+    float vf[NL][8];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool valid = (rbase + i * RPL) < end;
+      float2 t0 = unpack2<T>(vv[i].x), t1 = unpack2<T>(vv[i].y), t2 = unpack2<T>(vv[i].z), t3 = unpack2<T>(vv[i].w);
+      vf[i][0] = valid ? t0.x : 0.f; vf[i][1] = valid ? t0.y : 0.f;
+      vf[i][2] = valid ? t1.x : 0.f; vf[i][3] = valid ? t1.y : 0.f;
+      vf[i][4] = valid ? t2.x : 0.f; vf[i][5] = valid ? t2.y : 0.f;
+      vf[i][6] = valid ? t3.x : 0.f; vf[i][7] = valid ? t3.y : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float mx = m[g];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) mx = fmaxf(mx, sc[i][g]);
+      const float mxs = (mx == -INFINITY) ? 0.f : mx;
+      const float alpha = __expf(m[g] - mxs);
+      float p[NL];
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        p[i] = __expf(sc[i][g] - mxs);
+        ps += p[i];
+      }
+      l[g] = l[g] * alpha + ps;
+      m[g] = mx;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        float a = acc[g][d] * alpha;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) a = fmaf(p[i], vf[i][d], a);
+        acc[g][d] = a;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float mo = __shfl_xor(m[g], off, 64);
+      const float lo = __shfl_xor(l[g], off, 64);
+      const float mx = fmaxf(m[g], mo);
+      const float mxs = (mx == -INFINITY) ? 0.f : mx;
+      const float a0 = __expf(m[g] - mxs), a1 = __expf(mo - mxs);
+      l[g] = l[g] * a0 + lo * a1;
+      m[g] = mx;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float ao = __shfl_xor(acc[g][d], off, 64);
+        acc[g][d] = acc[g][d] * a0 + ao * a1;
+      }
+    }
+  }
+  if (c == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (dl == 0) {
+        s_m[wave * G + g] = m[g];
+        s_l[wave * G + g] = l[g];
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) s_acc[(wave * G + g) * D + dl * 8 + d] = acc[g][d];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += NW * 64) {
+    const int g = idx / D, d = idx % D;
+    float M = s_m[g];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w * G + g]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float a = __expf(s_m[w * G + g] - M);  // M finite: wave 0 always owns a valid row
+      num += a * s_acc[(w * G + g) * D + d];
+      den += a * s_l[w * G + g];
+    }
+    const float o = num / den;
+    if (DIRECT) {
+      out[((size_t)b * HQ + h * G + g) * D + d] = to16<T>(o);
+    } else {
+      part_o[((size_t)(b * S + s) * HQ + h * G + g) * D + d] = o;
+      if (d == 0) part_lse[(size_t)(b * S + s) * HQ + h * G + g] = M + __logf(den);
+    }
+  }
+}
+
+template <int D, int G, int NW, int NL, int R>
+constexpr size_t ring_smem_bytes() {
+  return (size_t)NW * R * 2 * NL * 1024 + ((size_t)NW * G * D + 2 * NW * G) * sizeof(float);
+}
+
 // stage 2: LSE-weighted merge of the S partials of one (b, query head)   (reference :391-435)
+// 4 waves per (b, hq): every wave first reads all S lse values (<= 256), then waves take the splits
+// round-robin with independent, unrolled loads; the four partial sums meet in LDS.
+constexpr int DEC_MAX_SPLITS = 256;
 template <typename T, int D>
-__global__ __launch_bounds__(64) void decode_stage2_kernel(const float* __restrict__ part_o,
-                                                          const float* __restrict__ part_lse,
-                                                          uint16_t* __restrict__ out, int HQ, int S) {
-  constexpr int VPT = D / 64;  // values per thread
+__global__ __launch_bounds__(256) void decode_stage2_kernel(const float* __restrict__ part_o,
+                                                           const float* __restrict__ part_lse,
+                                                           uint16_t* __restrict__ out, int HQ, int S) {
+  constexpr int VPT = D / 64;  // values per lane
+  __shared__ float s_acc[4][D];
   const int bhq = blockIdx.x;
   const int b = bhq / HQ, hq = bhq % HQ;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float lse[DEC_MAX_SPLITS / 64];
   float M = -INFINITY;
-  for (int s = lane; s < S; s += 64) M = fmaxf(M, part_lse[(size_t)(b * S + s) * HQ + hq]);
+#pragma unroll
+  for (int j = 0; j < DEC_MAX_SPLITS / 64; ++j) {
+    const int s = lane + 64 * j;
+    lse[j] = s < S ? part_lse[(size_t)(b * S + s) * HQ + hq] : -INFINITY;
+    M = fmaxf(M, lse[j]);
+  }
   M = wave_reduce_max(M);
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < DEC_MAX_SPLITS / 64; ++j) {
+    lse[j] = (lse[j] == -INFINITY) ? 0.f : __expf(lse[j] - M);  // weight; empty splits (never written) -> 0
+    den += lse[j];
+  }
+  den = wave_reduce_sum(den);
   float acc[VPT];
 #pragma unroll
   for (int j = 0; j < VPT; ++j) acc[j] = 0.f;
-  float den = 0.f;
-  if (M != -INFINITY) {
-    for (int s = 0; s < S; ++s) {
-      const float lse = part_lse[(size_t)(b * S + s) * HQ + hq];
-      if (lse == -INFINITY) continue;  // empty split: its partial row was never written
-      const float w = __expf(lse - M);
-      const float* po = part_o + ((size_t)(b * S + s) * HQ + hq) * D + lane * VPT;
+  for (int s0 = 0; s0 < S; s0 += 16) {  // 4 independent partial rows per wave in flight
+    float w[4];
+    float v[4][VPT];
 #pragma unroll
-      for (int j = 0; j < VPT; ++j) acc[j] += w * po[j];
-      den += w;
+    for (int i = 0; i < 4; ++i) {
+      const int s = s0 + wave + 4 * i;
+      w[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < DEC_MAX_SPLITS / 64; ++j)
+        if ((s >> 6) == j) w[i] = __shfl(lse[j], s & 63, 64);
+      if (s >= S) w[i] = 0.f;
+      const int sc = s < S ? s : 0;  // clamp: always a valid address; weight 0 discards it
+      const float* po = part_o + ((size_t)(b * S + sc) * HQ + hq) * D + lane * VPT;
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) v[i][j] = po[j];
     }
-  }
-  const float inv = den > 0.f ? 1.f / den : 0.f;
-  uint16_t* o = out + ((size_t)b * HQ + hq) * D + lane * VPT;
 #pragma unroll
-  for (int j = 0; j < VPT; ++j) o[j] = to16<T>(acc[j] * inv);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) acc[j] += (w[i] != 0.f) ? w[i] * v[i][j] : 0.f;  // never 0 * garbage
+  }
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) s_acc[wave][lane * VPT + j] = acc[j];
+  __syncthreads();
+  if (tid < D) {
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+    const float v = (s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid]) * inv;
+    out[((size_t)b * HQ + hq) * D + tid] = to16<T>(v);
+  }
+}
+
+static int g_decode_variant = 0;  // tuning knob for tools/microbench.py (see launch_decode)
+
+template <typename T, int D, int G, int NL, int MINW>
+static int launch_decode_v(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
+                           const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
+                           float scale, int S, hipStream_t st) {
+  const int HQ = HKV * G;
+  float* part_o = ws;
+  float* part_lse = ws + (size_t)B * S * HQ * D;
+  dim3 grid(B * HKV * S), block(DEC_NW * 64);
+  if (S == 1) {
+    hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, true, NL, MINW>), grid, block, 0, st, (const uint16_t*)q,
+                       (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
+                       page_table, bmap, HKV, PS, NLP, S, scale);
+    return check_launch();
+  }
+  hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, false, NL, MINW>), grid, block, 0, st, (const uint16_t*)q,
+                     (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
+                     page_table, bmap, HKV, PS, NLP, S, scale);
+  hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
+                     (uint16_t*)out, HQ, S);
+  return check_launch();
+}
+
+static int g_decode_nt = 1;  // K/V are read once per step: non-temporal LDS-DMA measured 5-8% faster
+static int g_decode_nocompute = 0;
+
+template <typename T, int D, int G, int NW, int NL, int R, bool NT>
+static int launch_decode_ring_nt(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
+                              const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
+                              float scale, int S, hipStream_t st) {
+  const int HQ = HKV * G;
+  float* part_o = ws;
+  float* part_lse = ws + (size_t)B * S * HQ * D;
+  constexpr size_t smem = ring_smem_bytes<D, G, NW, NL, R>();
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  dim3 grid(B * HKV * S), block(NW * 64);
+  static bool attr_done[2] = {false, false};
+  if (S == 1) {
+    auto kern = decode_stage1_ring_kernel<T, D, G, true, NW, NL, R, NT>;
+    if (!attr_done[0]) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_done[0] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
+                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+    return check_launch();
+  }
+  if (g_decode_nocompute) {
+    auto kern = decode_stage1_ring_kernel<T, D, G, false, NW, NL, R, NT, true>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
+                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+    return check_launch();
+  }
+  auto kern = decode_stage1_ring_kernel<T, D, G, false, NW, NL, R, NT>;
+  if (!attr_done[1]) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done[1] = true;
+  }
+  hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
+                     (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+  hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
+                     (uint16_t*)out, HQ, S);
+  return check_launch();
+}
+
+template <typename T, int D, int G, int NW, int NL, int R>
+static int launch_decode_ring(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
+                              const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
+                              float scale, int S, hipStream_t st) {
+  if (g_decode_nt)
+    return launch_decode_ring_nt<T, D, G, NW, NL, R, true>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS,
+                                                           NLP, scale, S, st);
+  return launch_decode_ring_nt<T, D, G, NW, NL, R, false>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS,
+                                                          NLP, scale, S, st);
 }
 
 template <typename T, int D, int G>
 static int launch_decode(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
                          const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
                          float scale, int S, hipStream_t st) {
-  const int HQ = HKV * G;
-  float* part_o = ws;
-  float* part_lse = ws + (size_t)B * S * HQ * D;
-  dim3 grid(B * HKV * S), block(DEC_NW * 64);
-  if (S == 1) {
-    hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, true>), grid, block, 0, st, (const uint16_t*)q,
-                       (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
-                       page_table, bmap, HKV, PS, NLP, S, scale);
-    return check_launch();
+#define RING(NW_, NL_, R_) \
+  return launch_decode_ring<T, D, G, NW_, NL_, R_>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st)
+  if constexpr (D == 128 && G == 4) {  // the tuned shape: variants selectable for tools/microbench.py
+    switch (g_decode_variant) {
+      case 1: return launch_decode_v<T, D, G, 4, 2>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
+      case 2: RING(4, 4, 3);
+      case 3: RING(8, 2, 4);
+      case 4: RING(8, 4, 2);
+      case 5: RING(8, 2, 3);
+      case 6: RING(4, 2, 4);
+      case 7: RING(4, 2, 8);
+      default: RING(4, 4, 4);
+    }
   }
-  hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, false>), grid, block, 0, st, (const uint16_t*)q,
-                     (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
-                     page_table, bmap, HKV, PS, NLP, S, scale);
-  hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(64), 0, st, part_o, part_lse,
-                     (uint16_t*)out, HQ, S);
-  return check_launch();
+  if constexpr (D <= 128) RING(4, 4, 4);
+  return launch_decode_v<T, D, G, 4, 2>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
+#undef RING
 }
 
 template <typename T, int D>
@@ -343,7 +738,9 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
                                  float sm_scale, int n_splits, int dtype, cvllm_stream_t stream) {
   if (!q || !k_cache || !v_cache || !out || !seq_lens_bh || !page_table || !batch_mapping) return CVLLM_ERR_ARG;
   if (B <= 0 || HQ <= 0 || HKV <= 0 || n_splits <= 0 || n_logical_pages_max <= 0) return CVLLM_ERR_ARG;
-  if (HQ % HKV != 0) return CVLLM_ERR_SHAPE;
+  if (HQ % HKV != 0 || n_splits > DEC_MAX_SPLITS) return CVLLM_ERR_SHAPE;
+  // the ring kernel keeps a split's page ids in 4 VGPRs (256 pages): rows per split <= 256 * page_size
+  if ((n_logical_pages_max + n_splits - 1) / n_splits + 1 > 64 * DEC_PGREGS) return CVLLM_ERR_SHAPE;
   // a unit of (64/(D/8))*4 rows must not straddle a page; the reference requires PAGE_SIZE % 32 == 0 (:80)
   if (page_size <= 0 || page_size % 32 != 0) return CVLLM_ERR_SHAPE;
   if (n_splits > 1) {
@@ -359,6 +756,8 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
                             (float*)workspace, B, HKV, page_size, n_logical_pages_max, sm_scale, n_splits, st);
   return CVLLM_ERR_SHAPE;
 }
+
+extern "C" void cvllm_debug_set_decode_variant(int v) { g_decode_variant = v & 0xff; g_decode_nt = ((v >> 8) & 1) ^ 1; g_decode_nocompute = (v >> 9) & 1; }
 
 // Host restatement of num_splits_heuristic (cv/attention/sparse_decode_kernel.py:169-192).
 extern "C" int cvllm_num_splits(int total_mblocks, int max_seq_len, int num_sms, int max_splits) {

@@ -1,0 +1,360 @@
+// a1 — causal varlen prefill attention over [paged per-head prefix || appended block], GQA, gfx950 MFMA.
+//
+// Replaces cv/attention/sparse_varlen_kernel.py:277-519 (_causal_head_sparse_varlen_with_cache).
+//
+// Tiling (wave64, 8 waves = 512 threads per workgroup, 2 waves per SIMD):
+//   * a workgroup owns one (sequence b, kv-head g, query tile): 256 rows = (256/G tokens) x G query heads, so
+//     every K/V tile staged in LDS is shared by all G heads of the group (the reference's M = BLOCK_M*G packing);
+//     a wave owns 32 rows and keeps their Q fragments in registers (B operand of the swapped product).
+//   * K/V are consumed in 64-key tiles, double-buffered in LDS (2 x (16 + 16) KiB), staged through registers:
+//     the global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them.
+//   * S^T = K Q^T with v_mfma_f32_32x32x16 (keys on the accumulator ROW, the query on the lane): the row softmax
+//     of a query is in-lane (+ one exchange with lane^32), and the fp32 accumulator registers 8s..8s+7 converted
+//     to 16-bit ARE the B operand of the next product O^T += V^T P^T (no LDS round trip for P).
+//   * V^T fragments come from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose); the K tile is
+//     read row-wise with ds_read_b128.  Both images use 256-byte rows with XOR-swizzled 16-byte chunks.
+//   * online softmax in the exp2 domain (scale*log2e folded into one FMA per logit), masked logits = -inf,
+//     P rounded to the model dtype before PV like the reference (:398), fp32 accumulate, one divide at the end.
+//   * O^T goes through LDS so that the global store is whole 256-byte rows.
+// Grid order: kv-head fastest (blockIdx % 8 = XCD label -> all query tiles of one kv-head share an L2),
+// heaviest (last) query tiles first for causal load balance.
+#include "common.h"
+
+namespace cvllm {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <typename T>
+__device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 mfma32<F16>(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 mfma32<BF16>(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+constexpr int PF_ROWS = 256;   // query rows per workgroup
+constexpr int PF_KT = 64;      // keys per tile
+constexpr int PF_THREADS = 512;
+constexpr int PF_TILE_BYTES = PF_KT * 256;        // one K or V tile image (256-byte rows)
+constexpr int PF_OSTRIDE = 272;                   // padded row stride of the O staging image
+constexpr int PF_SMEM = (4 * PF_TILE_BYTES > 8 * 32 * PF_OSTRIDE) ? 4 * PF_TILE_BYTES : 8 * 32 * PF_OSTRIDE;
+
+// K image: row-wise ds_read_b128 (T2 swizzle);  V image: transposed ds_read_b64_tr_b16 (guide T10 layout (b))
+__device__ __forceinline__ uint32_t k_off(int row, int ch) { return row * 256 + 16 * (ch ^ (row & 15)); }
+__device__ __forceinline__ uint32_t v_off(int row, int ch) {
+  return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <typename T, int D, int G>
+__global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, int64_t sq_n,
+    int64_t sk_n, int64_t sk_h, int64_t sv_n, int64_t sv_h, const uint16_t* __restrict__ kc,
+    const uint16_t* __restrict__ vc, uint16_t* __restrict__ out, const int* __restrict__ seq_lens,
+    const int* __restrict__ page_table, const int* __restrict__ bmap, const int* __restrict__ cu, int B, int HKV,
+    int PS, int NLP, float scale_log2e) {
+  constexpr int BM = PF_ROWS / G;  // tokens per query tile
+  constexpr int KS = D / 16;       // k-steps of the QK^T product
+  constexpr int DB = D / 32;       // 32-wide blocks of the head dim
+  constexpr int CH = D / 8;        // 16-byte chunks per row
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int bid = blockIdx.x;
+  const int g = bid % HKV;
+  const int b = (bid / HKV) % B;
+  const int tile_rev = bid / (HKV * B);
+  const int s0 = cu[b];
+  const int La = cu[b + 1] - s0;
+  const int nqt = (La + BM - 1) / BM;
+  if (tile_rev >= nqt) return;
+  const int qt = nqt - 1 - tile_rev;  // heaviest tiles first
+  const int m0 = qt * BM;
+  const int HQ = HKV * G;
+
+  const int Lc = seq_lens[b * HKV + g];
+  const int* pt = page_table + ((size_t)bmap[b] * HKV + g) * NLP;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int row = wave * 32 + r;            // query row inside the tile
+  const int head_local = row / BM;
+  const int tok = m0 + row % BM;            // local token index of this lane's query
+  const bool valid_q = tok < La;
+  const int hq = g * G + head_local;
+
+  // ---- Q fragments (B operand: lane holds Q[q = r][dims 16s + 8h .. +8]) ---------------------------------
+  s16x8 qf[KS];
+  {
+    const uint16_t* qp = q + (size_t)(s0 + (valid_q ? tok : 0)) * sq_n + (size_t)hq * D + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+      qf[s] = __builtin_bit_cast(s16x8, t);
+    }
+  }
+
+  const int ntc = (Lc + PF_KT - 1) / PF_KT;                       // cached-prefix tiles
+  const int la_vis = min(m0 + BM, La);                            // appended keys visible to this query tile
+  const int nta = (la_vis + PF_KT - 1) / PF_KT;                   // appended tiles (last ones are on the diagonal)
+  const int ntiles = ntc + nta;
+
+  // ---- staging: thread -> (rows srow, srow+32; chunk sch) of the K and V tiles ---------------------------------
+  const int sch = tid & 15;
+  const int srow = tid >> 4;  // 0..31
+  const bool stage_active = sch < CH;
+  uint4 kreg[2], vreg[2];
+
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int jj = srow + 32 * i;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (stage_active) {
+        if (t < ntc) {
+          const int pos = t * PF_KT + jj;
+          if (pos < Lc) {
+            const size_t rowp = (size_t)pt[pos / PS] * PS + pos % PS;  // int64 row offset (reference :371)
+            kv = *reinterpret_cast<const uint4*>(kc + rowp * D + sch * 8);
+            vv = *reinterpret_cast<const uint4*>(vc + rowp * D + sch * 8);
+          }
+        } else {
+          const int pos = (t - ntc) * PF_KT + jj;
+          if (pos < la_vis) {
+            const size_t n = (size_t)(s0 + pos);
+            kv = *reinterpret_cast<const uint4*>(k + n * sk_n + (size_t)g * sk_h + sch * 8);
+            vv = *reinterpret_cast<const uint4*>(v + n * sv_n + (size_t)g * sv_h + sch * 8);
+          }
+        }
+      }
+      kreg[i] = kv;  // rows past the end are ZERO (P = 0 times garbage must not make NaN)
+      vreg[i] = vv;
+    }
+  };
+  auto lstore = [&](int buf) {
+    if (stage_active) {
+      char* kb = smem + buf * 2 * PF_TILE_BYTES;
+      char* vb = kb + PF_TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int jj = srow + 32 * i;
+        *reinterpret_cast<uint4*>(kb + k_off(jj, sch)) = kreg[i];
+        *reinterpret_cast<uint4*>(vb + v_off(jj, sch)) = vreg[i];
+      }
+    }
+  };
+
+  // ---- accumulators --------------------------------------------------------------------------------------------
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+  float m_run = -INFINITY;  // running max (exp2 domain), identical in lanes l and l^32
+  float l_run = 0.f;        // running sum of this lane's half of the keys
+
+  // per-lane constant parts of the LDS addresses
+  const int gi = lane >> 4;       // 16-lane group
+  const int li = lane & 15;
+  const int tq = li >> 2, tp = li & 3;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) gload(t + 1);
+
+    const char* kb = smem + buf * 2 * PF_TILE_BYTES;
+    const char* vb = kb + PF_TILE_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks --------------------------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[kb2][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 a = *reinterpret_cast<const uint4*>(kb + k_off(kb2 * 32 + r, 2 * s + h));
+        sacc[kb2] = mfma32<T>(__builtin_bit_cast(s16x8, a), qf[s], sacc[kb2]);
+      }
+    }
+
+    // ---- masking + online softmax (lane = one query; rows of the accumulator = keys) -----------------------
+    const bool cached = t < ntc;
+    const int j0 = cached ? t * PF_KT : (t - ntc) * PF_KT;
+    const int count = cached ? min(PF_KT, Lc - j0) : min(PF_KT, la_vis - j0);
+    const bool need_mask = count < PF_KT || (!cached && j0 + PF_KT - 1 > m0);  // wave-uniform
+    float x[2][16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float val = sacc[kb2][i] * scale_log2e;
+        if (need_mask) {
+          const int kk = kb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const bool vis = kk < count && (cached || (j0 + kk) <= tok);
+          val = vis ? val : -INFINITY;
+        }
+        x[kb2][i] = val;
+        mx = fmaxf(mx, val);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    m_run = m_new;
+    float psum = 0.f;
+    s16x8 pf[4];
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint32_t w[4];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          const float p0 = __builtin_amdgcn_exp2f(x[kb2][8 * s2 + 2 * jp] - m_safe);
+          const float p1 = __builtin_amdgcn_exp2f(x[kb2][8 * s2 + 2 * jp + 1] - m_safe);
+          w[jp] = pack2<T>(p0, p1);
+          // row sum from the fp32 probabilities, P itself rounded to the model dtype (reference :398-400)
+          psum += p0 + p1;
+        }
+        pf[kb2 * 2 + s2] = __builtin_bit_cast(s16x8, make_uint4(w[0], w[1], w[2], w[3]));
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+
+    // ---- O^T += V^T P^T : 4 k-steps of 16 keys, DB blocks of 32 dims --------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int r0 = (ks >> 1) * 32 + (ks & 1) * 16 + 4 * (gi >> 1);  // first key row of this lane group's block
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const int c0 = (db * 2 + (gi & 1)) * 2;  // first 16-byte chunk of the block's 16 columns
+        const uint32_t a0 = v_off(r0 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
+        const uint32_t a1 = v_off(r0 + 8 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a1));
+        const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[db] = mfma32<T>(a, pf[ks], oacc[db]);
+      }
+    }
+
+    if (t + 1 < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  char* ob = smem + wave * (32 * PF_OSTRIDE);
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int d = db * 32 + 8 * i4 + 4 * h;  // accumulator rows (i&3)+8*(i>>2)+4h for i = 4*i4 .. 4*i4+3
+      const uint32_t w0 = pack2<T>(oacc[db][4 * i4] * inv, oacc[db][4 * i4 + 1] * inv);
+      const uint32_t w1 = pack2<T>(oacc[db][4 * i4 + 2] * inv, oacc[db][4 * i4 + 3] * inv);
+      *reinterpret_cast<uint2*>(ob + r * PF_OSTRIDE + d * 2) = make_uint2(w0, w1);
+    }
+  }
+  // the wave re-reads only what it wrote itself: LDS ops of one wave execute in order, no barrier needed
+  constexpr int RPI = 64 / CH;          // rows per store instruction
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int rr = it * RPI + lane / CH;
+    const int ch = lane % CH;
+    const int grow = wave * 32 + rr;
+    const int ghead = g * G + grow / BM;
+    const int gtok = m0 + grow % BM;
+    if (gtok < La) {
+      const uint4 val = *reinterpret_cast<const uint4*>(ob + rr * PF_OSTRIDE + ch * 16);
+      *reinterpret_cast<uint4*>(out + ((size_t)(s0 + gtok) * HQ + ghead) * D + ch * 8) = val;
+    }
+  }
+}
+
+template <typename T, int D, int G>
+static int launch_prefill(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                          int64_t sv_n, int64_t sv_h, const void* kc, const void* vc, void* out, const int* seq_lens,
+                          const int* page_table, const int* bmap, const int* cu, int B, int max_seqlen_q, int HKV,
+                          int PS, int NLP, float scale, hipStream_t st) {
+  constexpr int BM = PF_ROWS / G;
+  const int nqt = (max_seqlen_q + BM - 1) / BM;
+  auto kern = prefill_attn_kernel<T, D, G>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PF_SMEM);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nqt * B * HKV), dim3(PF_THREADS), PF_SMEM, st, (const uint16_t*)q, (const uint16_t*)k,
+                     (const uint16_t*)v, sq_n, sk_n, sk_h, sv_n, sv_h, (const uint16_t*)kc, (const uint16_t*)vc,
+                     (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP, scale * 1.4426950408889634f);
+  return check_launch();
+}
+
+template <typename T, int D>
+static int prefill_dispatch_g(int G, const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n,
+                              int64_t sk_h, int64_t sv_n, int64_t sv_h, const void* kc, const void* vc, void* out,
+                              const int* seq_lens, const int* page_table, const int* bmap, const int* cu, int B,
+                              int max_seqlen_q, int HKV, int PS, int NLP, float scale, hipStream_t st) {
+#define PF_CALL(G_) \
+  launch_prefill<T, D, G_>(q, k, v, sq_n, sk_n, sk_h, sv_n, sv_h, kc, vc, out, seq_lens, page_table, bmap, cu, B, \
+                           max_seqlen_q, HKV, PS, NLP, scale, st)
+  switch (G) {
+    case 1: return PF_CALL(1);
+    case 2: return PF_CALL(2);
+    case 4: return PF_CALL(4);
+    case 8: return PF_CALL(8);
+    default: return CVLLM_ERR_SHAPE;
+  }
+#undef PF_CALL
+}
+
+}  // namespace cvllm
+
+using namespace cvllm;
+
+extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n,
+                                  int64_t sk_h, int64_t sv_n, int64_t sv_h, const void* k_cache, const void* v_cache,
+                                  void* out, const int32_t* seq_lens_bh, const int32_t* page_table,
+                                  const int32_t* batch_mapping, const int32_t* cu_seqlens_q, int B, int total_tokens,
+                                  int max_seqlen_q, int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
+                                  float sm_scale, int dtype, cvllm_stream_t stream) {
+  if (!q || !k || !v || !k_cache || !v_cache || !out || !seq_lens_bh || !page_table || !batch_mapping ||
+      !cu_seqlens_q)
+    return CVLLM_ERR_ARG;
+  if (B <= 0 || total_tokens < 0 || HQ <= 0 || HKV <= 0 || page_size <= 0 || n_logical_pages_max <= 0)
+    return CVLLM_ERR_ARG;
+  if (HQ % HKV != 0) return CVLLM_ERR_SHAPE;
+  if (total_tokens == 0 || max_seqlen_q <= 0) return CVLLM_OK;
+  // 16-byte vector loads: every row start must be 16-byte aligned
+  if ((sq_n % 8) || (sk_n % 8) || (sk_h % 8) || (sv_n % 8) || (sv_h % 8)) return CVLLM_ERR_SHAPE;
+  const int G = HQ / HKV;
+  hipStream_t st = (hipStream_t)stream;
+#define PF_D(T_, D_)                                                                                              \
+  return prefill_dispatch_g<T_, D_>(G, q, k, v, sq_n, sk_n, sk_h, sv_n, sv_h, k_cache, v_cache, out, seq_lens_bh, \
+                                    page_table, batch_mapping, cu_seqlens_q, B, max_seqlen_q, HKV, page_size,     \
+                                    n_logical_pages_max, sm_scale, st)
+  if (dtype == CVLLM_F16) {
+    if (D == 128) PF_D(F16, 128);
+    if (D == 64) PF_D(F16, 64);
+  } else if (dtype == CVLLM_BF16) {
+    if (D == 128) PF_D(BF16, 128);
+    if (D == 64) PF_D(BF16, 64);
+  }
+#undef PF_D
+  return CVLLM_ERR_SHAPE;
+}

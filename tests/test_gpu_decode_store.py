@@ -251,11 +251,17 @@ def test_ranked_store_golden(dev, name):
                           PAD_TO_PAGE_SIZE=bool(c["pad"]), cu_seqlens_k=cu)
     torch.cuda.synchronize()
     assert torch.equal(l.cpu(), c["bh_lens"])
-    kcc, B = kc.cpu(), l.shape[0]
+    kcc, vcc, B = kc.cpu(), vc.cpu(), l.shape[0]
+    offs = c["kept_offs"].tolist()
+    i = 0
     for b in range(B):
         for h in range(H):
             L1 = int(c["bh_lens"][b, h])
+            toks = c["kept_flat"][offs[i] : offs[i + 1]].tolist()  # the REFERENCE's retained set of (b,h)
+            i += 1
             rows = O.cache_rows(c["page_table"][int(c["batch_mapping"][b]), h], L1, PS)
-            a = sorted(map(tuple, kcc[rows].float().tolist()))
-            r = sorted(map(tuple, c["k_cache"][rows].float().tolist()))
-            assert a == r
+            src = [int(c["cu_seqlens_k"][b]) + t for t in toks]
+            for cache, new in ((kcc, c["keys"]), (vcc, c["vals"])):
+                a = sorted(map(tuple, cache[rows].float().tolist()))
+                r = sorted(map(tuple, new[src, h].float().tolist()))
+                assert a == r

@@ -52,20 +52,23 @@ def bench_decode(args):
     layers = max(1, min(32, int(600e6 // (2 * B * HKV * L * D * 2)) + 1))
     caches, pt, bm, lens = build_cache(B, HKV, D, PS, L, dtype, dev, layers)
     q = torch.randn(B, HQ, D, device=dev, dtype=dtype)
-    splits_list = [args.splits] if args.splits else [1, 4, 8, 16, 32, 48, 64, 96, 128]
+    splits_list = [args.splits] if args.splits else [16, 32, 64]
     bytes_alg = 2 * D * 2 * B * HKV * L + 2 * B * HQ * D * 2
-    for S in splits_list:
-        dk.plan_internal_splits = lambda n_bh, bound, ks, S=S: S
-        i = [0]
-
-        def fn():
-            kc, vc = caches[i[0] % layers]
-            i[0] += 1
-            dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS)
-
-        us = time_fn(fn)
-        print(f"decode B={B} L={L} splits={S:3d} layers={layers}: {us:8.2f} us/launch(+merge)  "
-              f"{bytes_alg / us / 1e6:7.3f} TB/s algorithmic", flush=True)
+    from compactor_vllm_amd import _lib
+    for variant in ([args.variant] if args.variant >= 0 else [0, 1, 2, 3, 4, 5, 6, 7, 0x100, 0x103]):
+        _lib.lib().cvllm_debug_set_decode_variant(variant)
+        for S in splits_list:
+            dk.plan_internal_splits = lambda n_bh, bound, ks, S=S: S
+            # one HIP graph with `layers` launches over distinct caches: no host launch overhead in the timing
+            dk.head_sparse_decode_attention(q, caches[0][0], caches[0][1], lens, pt, bm, HKV, PS)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for kc, vc in caches:
+                    out = dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS)
+            us = time_fn(g.replay, iters=20, warmup=3) / layers
+            print(f"decode variant={variant} B={B} L={L} splits={S:3d} layers={layers}: {us:8.2f} us/(stage1+merge)  "
+                  f"{bytes_alg / us / 1e6:7.3f} TB/s algorithmic", flush=True)
 
 
 if __name__ == "__main__":
@@ -74,5 +77,6 @@ if __name__ == "__main__":
     ap.add_argument("--L", type=int, default=16384)
     ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=-1)
     a = ap.parse_args()
     {"decode": bench_decode}[a.what](a)
