@@ -1,0 +1,89 @@
+"""SnapKV query-aware key scoring on MI355X HIP kernels.
+
+Mirror of the reference module `compactor_vllm/compression/snapkv.py`: `SnapKVCompression` (:12-36)
+and `query_aware_key_scores` (:332-448) keep their names, argument order and defaults.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from ..utils.helpers import maybe_execute_in_stream
+from .common import BaseCompressionMethod
+from .compactor import zscore_segments_
+
+
+class SnapKVCompression(BaseCompressionMethod):
+    @staticmethod
+    def pre_rope_scoring(q, k, v, context) -> Optional[torch.Tensor]:
+        return None
+
+    @staticmethod
+    def post_rope_scoring(q, k, v, pre_rope_scores, context) -> Optional[torch.Tensor]:
+        return maybe_execute_in_stream(
+            query_aware_key_scores,
+            q,
+            k,
+            context.cu_seqlens_q,
+            context.cu_seqlens_k,
+            w=32,
+            max_seqlen_k=context.max_seqlen_k,
+            STORE_STREAM=context.STORE_STREAM,
+        )
+
+
+def query_aware_key_scores(
+    q: torch.Tensor,  # [N_q, Hq, D]
+    k: torch.Tensor,  # [N_k, Hk, D]
+    cu_seqlens_q: torch.Tensor,  # [B+1], int32
+    cu_seqlens_k: torch.Tensor,  # [B+1], int32
+    w: int,
+    sm_scale: float = None,  # defaults to 1/sqrt(D)
+    *,
+    accum_scores: torch.Tensor = None,
+    accum_blending: float = None,
+    normalize: bool = False,
+    max_seqlen_k: int = None,
+) -> Optional[torch.Tensor]:
+    """s_j = sum over the last `w` queries x G heads of softmax_row(q k^T / sqrt D) restricted to keys
+    [0, L-w); trailing 5-tap mean clipped at 128-key tiles (reference BLOCK_K pinned to 128);
+    last w keys <- +inf.  fp32 [N_k, Hk].  Only an int window is supported (the engine passes w=32).
+    `max_seqlen_k` avoids a host sync; when omitted it is read from cu_seqlens_k (one sync, like the
+    reference's `w.max().item()`).  Sequences with L <= w come back all +inf (reference: uninitialised)."""
+    assert q.stride(-1) == 1 and k.stride(-1) == 1, "last dim must be contiguous"
+    assert isinstance(w, int), "per-sequence window tensors are not supported"
+    _lib.require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
+    N_q, Hq, D = q.shape
+    N_k, Hk, Dk = k.shape
+    assert (Hq % Hk) == 0, "Hq must be a multiple of Hk"
+    assert q.stride(1) == D
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    B = cu_seqlens_q.numel() - 1
+    assert B == cu_seqlens_k.numel() - 1
+    if w * (Hq // Hk) == 0:
+        return torch.zeros((N_k, Hk), dtype=torch.float32, device=q.device)
+    cq, ck = _lib.i32(cu_seqlens_q), _lib.i32(cu_seqlens_k)
+    if max_seqlen_k is None:
+        max_seqlen_k = int(ck.diff().max().item())
+    out = torch.empty((N_k, Hk), dtype=torch.float32, device=q.device)
+    L = _lib.lib()
+    ws_bytes = L.cvllm_snapkv_workspace_bytes(B, Hk, w, int(max_seqlen_k))
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=q.device)
+    st = L.cvllm_snapkv_scores(
+        q.data_ptr(), k.data_ptr(), q.stride(0), k.stride(0), k.stride(1), out.data_ptr(), cq.data_ptr(), ck.data_ptr(),
+        B, Hq, Hk, D, int(w), float(sm_scale), 5, int(max_seqlen_k), _lib.dtype_code(q.dtype), ws.data_ptr(), ws_bytes,
+        _lib.stream(),
+    )
+    _lib.check(st, "cvllm_snapkv_scores")
+    if normalize:
+        raise NotImplementedError("windowed z-score (snapkv.py:279-329) is dead code upstream (normalize=False)")
+    if accum_scores is not None:
+        if accum_blending is not None:
+            accum_scores.mul_(accum_blending)
+        accum_scores.add_(out)
+        return accum_scores
+    return out

@@ -1,0 +1,694 @@
+// a5 / a6 / a7 / a8 — KV scoring kernels for gfx950.
+//
+// Replaces cv/compression/compactor.py: approximate_leverage_scores (:113-221, torch.matmul + batched SVD),
+// _zscore_per_batch_epilogue_no_window (:224-269), _non_causal_attn_kernel (:338-486) and
+// cv/compression/snapkv.py: _lse_and_store_logits_kernel (:39-157) + _scores_from_logits_kernel (:160-276).
+//
+// All of them are tiny next to the prefill attention they overlap with; the MFMA kernels reuse the register
+// fragment convention of prefill_attn.hip (32x32x16: lane = (row/col r = lane&31, k-half h = lane>>5)).
+#include "common.h"
+
+namespace cvllm {
+
+template <typename T>
+__device__ __forceinline__ f32x16 mfma32s(s16x8 a, s16x8 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 mfma32s<F16>(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 mfma32s<BF16>(s16x8 a, s16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+__device__ __forceinline__ uint32_t ktile_off(int row, int ch) { return row * 256 + 16 * (ch ^ (row & 15)); }
+
+// =====================================================================================================
+// a6: segmented z-score (+ optional blend with an accumulated score tensor), then protected-row fill
+// =====================================================================================================
+template <int DT>  // 0 f16, 1 bf16, 2 f32
+__device__ __forceinline__ float ld_score(const void* p, size_t i) {
+  if (DT == 2) return reinterpret_cast<const float*>(p)[i];
+  if (DT == 0) return from16<F16>(reinterpret_cast<const uint16_t*>(p)[i]);
+  return from16<BF16>(reinterpret_cast<const uint16_t*>(p)[i]);
+}
+template <int DT>
+__device__ __forceinline__ void st_score(void* p, size_t i, float v) {
+  if (DT == 2) reinterpret_cast<float*>(p)[i] = v;
+  else if (DT == 0) reinterpret_cast<uint16_t*>(p)[i] = to16<F16>(v);
+  else reinterpret_cast<uint16_t*>(p)[i] = to16<BF16>(v);
+}
+
+constexpr int ZS_T = 1024;
+template <int DT, int ADT>
+__global__ __launch_bounds__(ZS_T) void zscore_kernel(void* __restrict__ x, const int* __restrict__ cu, int H,
+                                                      const void* __restrict__ accum, float blend) {
+  __shared__ float s_a[ZS_T / 64], s_b[ZS_T / 64];
+  const int seg = blockIdx.x;
+  const size_t beg = (size_t)cu[seg] * H, end = (size_t)cu[seg + 1] * H;
+  if (end <= beg) return;
+  const int tid = threadIdx.x;
+  float sum = 0.f, sq = 0.f;
+  for (size_t i = beg + tid; i < end; i += ZS_T) {
+    const float v = ld_score<DT>(x, i);
+    sum += v;
+    sq += v * v;
+  }
+  sum = wave_reduce_sum(sum);
+  sq = wave_reduce_sum(sq);
+  if ((tid & 63) == 0) {
+    s_a[tid >> 6] = sum;
+    s_b[tid >> 6] = sq;
+  }
+  __syncthreads();
+  sum = 0.f;
+  sq = 0.f;
+#pragma unroll
+  for (int w = 0; w < ZS_T / 64; ++w) {
+    sum += s_a[w];
+    sq += s_b[w];
+  }
+  const float cnt = (float)(end - beg);
+  const float mean = sum / cnt;
+  const float var = fmaxf(sq / cnt - mean * mean, 0.f);  // biased, clamped, NO epsilon (compactor.py:258-260)
+  const float invstd = 1.0f / sqrtf(var);
+  for (size_t i = beg + tid; i < end; i += ZS_T) {
+    float v = (ld_score<DT>(x, i) - mean) * invstd;
+    if (accum) v += blend * ld_score<ADT>(accum, i);
+    st_score<DT>(x, i, v);
+  }
+}
+
+template <int DT>
+__global__ void fill_inf_kernel(void* __restrict__ x, const int* __restrict__ ranges, int H, int total_rows) {
+  const int lo = max(ranges[2 * blockIdx.x], 0), hi = min(ranges[2 * blockIdx.x + 1], total_rows);
+  for (size_t i = (size_t)lo * H + threadIdx.x; i < (size_t)hi * H; i += blockDim.x) st_score<DT>(x, i, INFINITY);
+}
+
+// =====================================================================================================
+// a7: chunked non-causal attention mass (Compactor post-RoPE score)
+//   per (sequence, 128-token chunk, kv-head): rows = tokens x G heads, keys = the chunk's tokens.
+//   pass 1 (S^T = K Q^T, query on the lane): exact row max / row sum of every query over all chunk keys.
+//   pass 2 (S = Q K^T, key on the lane): p = exp2(s*c - lse2[q]) summed over queries -> per-key mass.
+//   Same fragments for both passes, only the operand order swaps.
+// =====================================================================================================
+constexpr int CM_CHUNK = 128;
+template <typename T, int D, int G>
+__global__ __launch_bounds__(256) void chunk_mass_kernel(const uint16_t* __restrict__ q,
+                                                         const uint16_t* __restrict__ k, int64_t sq_n, int64_t sk_n,
+                                                         int64_t sk_h, float* __restrict__ mass,
+                                                         const int* __restrict__ cu, int B, int HKV, int nchunk_max,
+                                                         float scale_log2e, float pad_unit) {
+  constexpr int KS = D / 16;
+  constexpr int CH = D / 8;
+  constexpr int QB = G;  // 32-row query blocks per wave: rows = 128*G over 4 waves
+  __shared__ __attribute__((aligned(16))) char s_k[CM_CHUNK * 256];
+  __shared__ float s_mass[4][CM_CHUNK];
+
+  const int bid = blockIdx.x;
+  const int g = bid % HKV;
+  const int c = (bid / HKV) % nchunk_max;
+  const int b = bid / (HKV * nchunk_max);
+  const int s0 = cu[b], Lb = cu[b + 1] - s0;
+  const int t0 = c * CM_CHUNK;
+  if (t0 >= Lb) return;
+  const int M = min(CM_CHUNK, Lb - t0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+
+  // K tile -> LDS (rows >= M zero)
+  for (int e = tid; e < CM_CHUNK * CH; e += 256) {
+    const int row = e / CH, ch = e % CH;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row < M) val = *reinterpret_cast<const uint4*>(k + (size_t)(s0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
+    *reinterpret_cast<uint4*>(s_k + ktile_off(row, ch)) = val;
+  }
+  __syncthreads();
+
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};  // key = kb*32 + r, this lane's half of the query rows
+#pragma unroll 1
+  for (int qb = 0; qb < QB; ++qb) {
+    const int row = (wave * QB + qb) * 32 + r;  // row in [0, 128*G): head = row / 128, token = row % 128
+    const int head = row / CM_CHUNK, tok = row % CM_CHUNK;
+    const bool valid_q = tok < M;
+    s16x8 qf[KS];
+    {
+      const uint16_t* qp = q + (size_t)(s0 + t0 + (valid_q ? tok : 0)) * sq_n + (size_t)(g * G + head) * D + 8 * h;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+        qf[s] = __builtin_bit_cast(s16x8, t);
+      }
+    }
+    // pass 1: queries on lanes
+    float mx = -INFINITY;
+    f32x16 acc[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+        acc[kb] = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[s], acc[kb]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float val = kk < M ? acc[kb][i] * scale_log2e : -INFINITY;
+        acc[kb][i] = val;
+        mx = fmaxf(mx, val);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(acc[kb][i] - mx);
+    sum += __shfl_xor(sum, 32, 64);
+    // lse in the exp2 domain; invalid query rows get +inf so that they contribute p = 0 in pass 2
+    const float lse2 = valid_q ? mx + __builtin_amdgcn_logf(sum) : INFINITY;  // v_log_f32 = log2
+
+    // pass 2: keys on lanes, query rows in the accumulator registers
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x16 a2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a2[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+        a2 = mfma32s<T>(qf[s], __builtin_bit_cast(s16x8, a), a2);
+      }
+      float cs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qrow = (i & 3) + 8 * (i >> 2) + 4 * h;  // query row of this register
+        const float l2 = __shfl(lse2, qrow, 64);           // lanes qrow and qrow+32 hold the same value
+        cs += __builtin_amdgcn_exp2f(a2[i] * scale_log2e - l2);
+      }
+      colsum[kb] += cs;
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const float v = colsum[kb] + __shfl_xor(colsum[kb], 32, 64);
+    if (h == 0) s_mass[wave][kb * 32 + r] = v;
+  }
+  __syncthreads();
+  if (tid < M) {
+    // + the reference's padded-row term: every padding row of a 64-row query tile adds 1/chunk per key (:385,:477)
+    const float pad_rows = (float)(((M + 63) / 64) * 64 - M) * (float)G;
+    mass[(size_t)(s0 + t0 + tid) * HKV + g] =
+        s_mass[0][tid] + s_mass[1][tid] + s_mass[2][tid] + s_mass[3][tid] + pad_rows * pad_unit;
+  }
+}
+
+// =====================================================================================================
+// a5: leverage scores.  K1: X = K_h PHI (MFMA, fp32 out).  K2: per (chunk, head): centre, Gram + reg*I,
+// Cholesky, Ginv, score_i = xc_i^T Ginv xc_i  (all fp32).
+// =====================================================================================================
+constexpr int LV_KMAX = 64;  // sketch columns padded to two 32-wide MFMA blocks
+template <typename T, int D>
+__global__ __launch_bounds__(256) void sketch_kernel(const uint16_t* __restrict__ key, int64_t s_n, int64_t s_h,
+                                                     const uint16_t* __restrict__ phi, float* __restrict__ X, int N,
+                                                     int HKV, int kdim) {
+  constexpr int KS = D / 16;
+  __shared__ uint16_t s_phiT[LV_KMAX][D + 8];  // PHI^T, zero padded to 64 columns
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < LV_KMAX * D; e += 256) {
+    const int col = e / D, d = e % D;
+    s_phiT[col][d] = col < kdim ? phi[(size_t)d * kdim + col] : (uint16_t)0;
+  }
+  __syncthreads();
+  s16x8 pf[2][KS];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      pf[cb][s] = *reinterpret_cast<const s16x8*>(&s_phiT[cb * 32 + r][16 * s + 8 * h]);
+
+  const long nblk = ((long)N + 31) / 32;
+  for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk * HKV; blk += (long)gridDim.x * 4) {
+    const int hh = (int)(blk % HKV);
+    const long n0 = (blk / HKV) * 32;
+    const long n = n0 + r;
+    const bool valid = n < N;
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    const uint16_t* kp = key + (size_t)(valid ? n : 0) * s_n + (size_t)hh * s_h + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4 a = valid ? *reinterpret_cast<const uint4*>(kp + 16 * s) : make_uint4(0, 0, 0, 0);
+      acc[0] = mfma32s<T>(__builtin_bit_cast(s16x8, a), pf[0][s], acc[0]);
+      acc[1] = mfma32s<T>(__builtin_bit_cast(s16x8, a), pf[1][s], acc[1]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = cb * 32 + r;
+      if (col < kdim) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long nn = n0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (nn < N) X[((size_t)hh * N + nn) * kdim + col] = acc[cb][i];
+        }
+      }
+    }
+  }
+}
+
+constexpr int LV_KD = 48;   // supported sketch dim (LLMConfig.leverage_sketch_size default, engine_config.py)
+constexpr int LV_LD = 49;   // padded leading dimension in LDS
+__global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __restrict__ X, float* __restrict__ scores,
+                                                             const int* __restrict__ chunk_cu, int N, int HKV,
+                                                             float reg) {
+  __shared__ float s_mean[LV_KD];
+  __shared__ float s_G[LV_KD * LV_LD];    // Gram -> Cholesky factor L (lower)
+  __shared__ float s_Li[LV_KD * LV_LD];   // L^-1 (lower)
+  __shared__ float s_Gi[LV_KD * LV_LD];   // G^-1
+  __shared__ float s_tile[64 * LV_LD];    // 64 centred rows
+  const int cidx = blockIdx.x / HKV, hh = blockIdx.x % HKV;
+  const int beg = chunk_cu[cidx], end = chunk_cu[cidx + 1];
+  const int L = end - beg;
+  if (L <= 0) return;
+  const int tid = threadIdx.x;
+  const float* Xh = X + ((size_t)hh * N + beg) * LV_KD;
+
+  // column means: thread (col = tid % 48, slice = tid / 48) for tid < 240
+  {
+    float sum = 0.f;
+    const int col = tid % LV_KD, sl = tid / LV_KD;
+    if (tid < 5 * LV_KD)
+      for (int i = sl; i < L; i += 5) sum += Xh[(size_t)i * LV_KD + col];
+    s_tile[tid] = (tid < 5 * LV_KD) ? sum : 0.f;
+    __syncthreads();
+    if (tid < LV_KD) {
+      float t = 0.f;
+      for (int j = 0; j < 5; ++j) t += s_tile[j * LV_KD + tid];
+      s_mean[tid] = t / (float)L;
+    }
+    __syncthreads();
+  }
+  // Gram: thread owns 9 entries e = tid + 256*j  (48*48 = 2304 = 9*256)
+  float gacc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) gacc[j] = 0.f;
+  for (int i0 = 0; i0 < L; i0 += 64) {
+    const int rows = min(64, L - i0);
+    for (int e = tid; e < 64 * LV_KD; e += 256) {
+      const int rr = e / LV_KD, cc = e % LV_KD;
+      s_tile[rr * LV_LD + cc] = rr < rows ? Xh[(size_t)(i0 + rr) * LV_KD + cc] - s_mean[cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int e = tid + 256 * j;
+      const int a = e / LV_KD, bcol = e % LV_KD;
+      float t = gacc[j];
+      for (int rr = 0; rr < 64; ++rr) t = fmaf(s_tile[rr * LV_LD + a], s_tile[rr * LV_LD + bcol], t);
+      gacc[j] = t;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int e = tid + 256 * j;
+    const int a = e / LV_KD, bcol = e % LV_KD;
+    s_G[a * LV_LD + bcol] = gacc[j] + (a == bcol ? reg : 0.f);
+  }
+  __syncthreads();
+  // Cholesky (right-looking), whole workgroup, barrier per column
+  for (int j = 0; j < LV_KD; ++j) {
+    const float djj = sqrtf(s_G[j * LV_LD + j]);
+    __syncthreads();
+    if (tid == 0) s_G[j * LV_LD + j] = djj;
+    if (tid > j && tid < LV_KD) s_G[tid * LV_LD + j] /= djj;
+    __syncthreads();
+    for (int e = tid; e < LV_KD * LV_KD; e += 256) {
+      const int i = e / LV_KD, kcol = e % LV_KD;
+      if (kcol > j && i >= kcol) s_G[i * LV_LD + kcol] -= s_G[i * LV_LD + j] * s_G[kcol * LV_LD + j];
+    }
+    __syncthreads();
+  }
+  // L^-1 by forward substitution, one column per thread
+  if (tid < LV_KD) {
+    const int ccol = tid;
+    for (int i = 0; i < LV_KD; ++i) {
+      float t = (i == ccol) ? 1.f : 0.f;
+      for (int kk = ccol; kk < i; ++kk) t -= s_G[i * LV_LD + kk] * s_Li[kk * LV_LD + ccol];
+      s_Li[i * LV_LD + ccol] = (i < ccol) ? 0.f : t / s_G[i * LV_LD + i];
+    }
+  }
+  __syncthreads();
+  // G^-1 = L^-T L^-1
+  for (int e = tid; e < LV_KD * LV_KD; e += 256) {
+    const int a = e / LV_KD, bcol = e % LV_KD;
+    float t = 0.f;
+    for (int kk = max(a, bcol); kk < LV_KD; ++kk) t = fmaf(s_Li[kk * LV_LD + a], s_Li[kk * LV_LD + bcol], t);
+    s_Gi[a * LV_LD + bcol] = t;
+  }
+  __syncthreads();
+  // scores: one row per thread
+  for (int i = tid; i < L; i += 256) {
+    float xc[LV_KD];
+#pragma unroll
+    for (int cc = 0; cc < LV_KD; ++cc) xc[cc] = Xh[(size_t)i * LV_KD + cc] - s_mean[cc];
+    float sc = 0.f;
+    for (int a = 0; a < LV_KD; ++a) {
+      float t = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < LV_KD; ++cc) t = fmaf(s_Gi[a * LV_LD + cc], xc[cc], t);
+      // xc[a] with a runtime index would spill: recompute the a-th component from memory instead
+      sc = fmaf(t, Xh[(size_t)i * LV_KD + a] - s_mean[a], sc);
+    }
+    scores[(size_t)(beg + i) * HKV + hh] = fmaxf(sc, 0.f);
+  }
+}
+
+// =====================================================================================================
+// a8: SnapKV.  rows = last w queries x G heads of a sequence; keys = [0, L-w).
+//   K1 (grid b, g, key tile of 128): partial (max, sum) of every window row over the tile's keys.
+//   K2 (same grid): combine the partials to the exact lse of every row, recompute the tile's logits with the
+//       key on the lane, sum exp2(s - lse) over rows -> raw score of every key of the tile, then the
+//       trailing 5-tap mean clipped at the tile start (the reference's BLOCK_K, pinned to 128).
+// =====================================================================================================
+constexpr int SK_TILE = 128;
+constexpr int SK_MAXQB = 8;  // 32-row query blocks (w*G <= 256)
+template <typename T, int D, int G, bool PASS2>
+__global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                     int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                                                     float* __restrict__ scores, float* __restrict__ part,
+                                                     const int* __restrict__ cu_q, const int* __restrict__ cu_k,
+                                                     int B, int HKV, int w, int ntile_max, float scale_log2e,
+                                                     int pool) {
+  constexpr int KS = D / 16;
+  constexpr int CH = D / 8;
+  __shared__ __attribute__((aligned(16))) char s_k[SK_TILE * 256];
+  __shared__ float s_col[4][SK_TILE];
+  __shared__ float s_lse[SK_MAXQB * 32];
+
+  const int bid = blockIdx.x;
+  const int g = bid % HKV;
+  const int tile = (bid / HKV) % ntile_max;
+  const int b = bid / (HKV * ntile_max);
+  const int kb0 = cu_k[b], Lk = cu_k[b + 1] - kb0;
+  const int qend = cu_q[b + 1];
+  const int keff = Lk - w;  // keys that are scored
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int HQ = HKV * G;
+  (void)HQ;
+  if (keff <= 0) {  // L <= w: every key is "recent" -> +inf (the reference leaves these rows uninitialised)
+    if (PASS2 && tile == 0)
+      for (int i = tid; i < Lk; i += 256) scores[(size_t)(kb0 + i) * HKV + g] = INFINITY;
+    return;
+  }
+  const int t0 = tile * SK_TILE;
+  const int ntile = (keff + SK_TILE - 1) / SK_TILE;
+  if (tile >= ntile) return;
+  const int M = min(SK_TILE, keff - t0);
+  const int rows_b = w * G;
+  const int nqb = (rows_b + 31) / 32;
+
+  for (int e = tid; e < SK_TILE * CH; e += 256) {
+    const int row = e / CH, ch = e % CH;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row < M) val = *reinterpret_cast<const uint4*>(k + (size_t)(kb0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
+    *reinterpret_cast<uint4*>(s_k + ktile_off(row, ch)) = val;
+  }
+  if (PASS2) {
+    // exact lse of every window row from the per-tile partials (m, s) written by pass 1
+    for (int row = tid; row < nqb * 32; row += 256) {
+      float m = -INFINITY, ssum = 0.f;
+      if (row < rows_b) {
+        for (int t = 0; t < ntile; ++t) {
+          const float* pp = part + ((((size_t)b * HKV + g) * ntile_max + t) * (SK_MAXQB * 32) + row) * 2;
+          const float mt = pp[0], st = pp[1];
+          const float mn = fmaxf(m, mt);
+          ssum = ssum * __builtin_amdgcn_exp2f(m - mn) + st * __builtin_amdgcn_exp2f(mt - mn);
+          m = mn;
+        }
+      }
+      s_lse[row] = row < rows_b ? m + __builtin_amdgcn_logf(ssum) : INFINITY;
+    }
+  }
+  __syncthreads();
+
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int qb = wave; qb < nqb; qb += 4) {
+    // window row -> (query offset, local head): row = qoff*G + hq_local (snapkv.py:109-113)
+    const int row = qb * 32 + r;
+    const bool valid_q = row < rows_b;
+    const int qoff = row / G, hql = row % G;
+    s16x8 qf[KS];
+    {
+      const uint16_t* qp = q + (size_t)(qend - w + (valid_q ? qoff : 0)) * sq_n + (size_t)(g * G + hql) * D + 8 * h;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+        qf[s] = __builtin_bit_cast(s16x8, t);
+      }
+    }
+    if (!PASS2) {
+      float mx = -INFINITY;
+      f32x16 acc[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+          acc[kb] = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[s], acc[kb]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const float val = kk < M ? acc[kb][i] * scale_log2e : -INFINITY;
+          acc[kb][i] = val;
+          mx = fmaxf(mx, val);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(acc[kb][i] - mx);
+      sum += __shfl_xor(sum, 32, 64);
+      if (h == 0 && valid_q) {
+        float* pp = part + ((((size_t)b * HKV + g) * ntile_max + tile) * (SK_MAXQB * 32) + row) * 2;
+        pp[0] = mx;
+        pp[1] = sum;
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        f32x16 a2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a2[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+          a2 = mfma32s<T>(qf[s], __builtin_bit_cast(s16x8, a), a2);
+        }
+        float cs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int qrow = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          cs += __builtin_amdgcn_exp2f(a2[i] * scale_log2e - s_lse[qrow]);
+        }
+        colsum[kb] += cs;
+      }
+    }
+  }
+  if (PASS2) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float v = colsum[kb] + __shfl_xor(colsum[kb], 32, 64);
+      if (h == 0) s_col[wave][kb * 32 + r] = v;
+    }
+    __syncthreads();
+    if (tid < SK_TILE) s_col[0][tid] = s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid];
+    __syncthreads();
+    if (tid < M) {
+      // causal avg-pool, kernel `pool`, clipped at the tile start (snapkv.py:253-262 with BLOCK_K = 128)
+      const int lo = max(0, tid - (pool - 1));
+      float t = 0.f;
+      for (int j = lo; j <= tid; ++j) t += s_col[0][j];
+      scores[(size_t)(kb0 + t0 + tid) * HKV + g] = t / (float)(tid - lo + 1);
+    }
+    if (tile == 0)  // last w keys <- +inf (snapkv.py:267-276)
+      for (int i = tid; i < w; i += 256) scores[(size_t)(kb0 + keff + i) * HKV + g] = INFINITY;
+  }
+}
+
+}  // namespace cvllm
+
+using namespace cvllm;
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
+                                     const void* accum, int accum_dtype, float blend, const int32_t* prot_ranges,
+                                     int n_ranges, int total_rows, cvllm_stream_t stream) {
+  if (!x || (n_segments > 0 && !cu) || H <= 0 || n_segments < 0 || n_ranges < 0) return CVLLM_ERR_ARG;
+  if (score_dtype < 0 || score_dtype > 2 || (accum && (accum_dtype < 0 || accum_dtype > 2))) return CVLLM_ERR_SHAPE;
+  if (n_ranges > 0 && !prot_ranges) return CVLLM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_segments > 0) {
+#define ZS(DT, ADT) \
+  hipLaunchKernelGGL((zscore_kernel<DT, ADT>), dim3(n_segments), dim3(ZS_T), 0, st, x, cu, H, accum, blend)
+    const int adt = accum ? accum_dtype : 2;
+    switch (score_dtype * 3 + adt) {
+      case 0: ZS(0, 0); break;
+      case 1: ZS(0, 1); break;
+      case 2: ZS(0, 2); break;
+      case 3: ZS(1, 0); break;
+      case 4: ZS(1, 1); break;
+      case 5: ZS(1, 2); break;
+      case 6: ZS(2, 0); break;
+      case 7: ZS(2, 1); break;
+      default: ZS(2, 2); break;
+    }
+#undef ZS
+  }
+  if (n_ranges > 0) {
+    if (score_dtype == 0) hipLaunchKernelGGL((fill_inf_kernel<0>), dim3(n_ranges), dim3(256), 0, st, x, prot_ranges, H, total_rows);
+    else if (score_dtype == 1) hipLaunchKernelGGL((fill_inf_kernel<1>), dim3(n_ranges), dim3(256), 0, st, x, prot_ranges, H, total_rows);
+    else hipLaunchKernelGGL((fill_inf_kernel<2>), dim3(n_ranges), dim3(256), 0, st, x, prot_ranges, H, total_rows);
+  }
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+static int chunk_mass_g(int G, const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h, float* mass,
+                        const int* cu, int B, int HKV, int nchunk, float scale, hipStream_t st) {
+  const float c = scale * 1.4426950408889634f, pu = 1.0f / (float)CM_CHUNK;
+  dim3 grid(B * nchunk * HKV), block(256);
+#define CM(G_)                                                                                                     \
+  hipLaunchKernelGGL((chunk_mass_kernel<T, D, G_>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, \
+                     sk_n, sk_h, mass, cu, B, HKV, nchunk, c, pu)
+  switch (G) {
+    case 1: CM(1); break;
+    case 2: CM(2); break;
+    case 4: CM(4); break;
+    case 8: CM(8); break;
+    default: return CVLLM_ERR_SHAPE;
+  }
+#undef CM
+  return check_launch();
+}
+
+extern "C" int cvllm_chunk_attn_mass(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                                     float* mass, const int32_t* cu_seqlens, int B, int total_tokens, int max_seqlen,
+                                     int HQ, int HKV, int D, int chunk_size, float sm_scale, int dtype,
+                                     cvllm_stream_t stream) {
+  if (!q || !k || !mass || !cu_seqlens) return CVLLM_ERR_ARG;
+  if (B <= 0 || HQ <= 0 || HKV <= 0 || total_tokens < 0) return CVLLM_ERR_ARG;
+  if (HQ % HKV != 0 || chunk_size != CM_CHUNK) return CVLLM_ERR_SHAPE;  // reference hard-codes chunk 128 (:17)
+  if ((sq_n % 8) || (sk_n % 8) || (sk_h % 8)) return CVLLM_ERR_SHAPE;
+  if (total_tokens == 0 || max_seqlen <= 0) return CVLLM_OK;
+  const int G = HQ / HKV;
+  const int nchunk = (max_seqlen + CM_CHUNK - 1) / CM_CHUNK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVLLM_F16 && D == 128) return chunk_mass_g<F16, 128>(G, q, k, sq_n, sk_n, sk_h, mass, cu_seqlens, B, HKV, nchunk, sm_scale, st);
+  if (dtype == CVLLM_F16 && D == 64) return chunk_mass_g<F16, 64>(G, q, k, sq_n, sk_n, sk_h, mass, cu_seqlens, B, HKV, nchunk, sm_scale, st);
+  if (dtype == CVLLM_BF16 && D == 128) return chunk_mass_g<BF16, 128>(G, q, k, sq_n, sk_n, sk_h, mass, cu_seqlens, B, HKV, nchunk, sm_scale, st);
+  if (dtype == CVLLM_BF16 && D == 64) return chunk_mass_g<BF16, 64>(G, q, k, sq_n, sk_n, sk_h, mass, cu_seqlens, B, HKV, nchunk, sm_scale, st);
+  return CVLLM_ERR_SHAPE;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" size_t cvllm_leverage_workspace_bytes(int total_tokens, int HKV, int sketch_dim) {
+  if (total_tokens <= 0 || HKV <= 0 || sketch_dim <= 0) return 0;
+  return (size_t)total_tokens * HKV * sketch_dim * sizeof(float);
+}
+
+extern "C" int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_t s_h, const void* phi, float* scores,
+                                     const int32_t* chunk_cu, int n_chunks, int total_tokens, int HKV, int D,
+                                     int sketch_dim, float regularizer, int dtype, void* workspace,
+                                     size_t workspace_bytes, cvllm_stream_t stream) {
+  if (!key_states || !phi || !scores || !chunk_cu) return CVLLM_ERR_ARG;
+  if (n_chunks <= 0 || total_tokens <= 0 || HKV <= 0) return CVLLM_ERR_ARG;
+  if (sketch_dim != LV_KD) return CVLLM_ERR_SHAPE;
+  if ((s_n % 8) || (s_h % 8)) return CVLLM_ERR_SHAPE;
+  if (!workspace || workspace_bytes < cvllm_leverage_workspace_bytes(total_tokens, HKV, sketch_dim))
+    return CVLLM_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* X = (float*)workspace;
+  long wave_tiles = (((long)total_tokens + 31) / 32) * HKV;
+  int blocks = (int)((wave_tiles + 3) / 4);
+  if (blocks > 1024) blocks = 1024;
+#define SK(T_, D_)                                                                                                  \
+  hipLaunchKernelGGL((sketch_kernel<T_, D_>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)key_states, s_n, s_h, \
+                     (const uint16_t*)phi, X, total_tokens, HKV, sketch_dim)
+  if (dtype == CVLLM_F16 && D == 128) SK(F16, 128);
+  else if (dtype == CVLLM_F16 && D == 64) SK(F16, 64);
+  else if (dtype == CVLLM_BF16 && D == 128) SK(BF16, 128);
+  else if (dtype == CVLLM_BF16 && D == 64) SK(BF16, 64);
+  else return CVLLM_ERR_SHAPE;
+#undef SK
+  hipLaunchKernelGGL(leverage_solve_kernel, dim3(n_chunks * HKV), dim3(256), 0, st, X, scores, chunk_cu, total_tokens,
+                     HKV, regularizer);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" size_t cvllm_snapkv_workspace_bytes(int B, int HKV, int w, int max_seqlen_k) {
+  if (B <= 0 || HKV <= 0 || max_seqlen_k <= 0) return 0;
+  (void)w;
+  const size_t ntile = ((size_t)max_seqlen_k + SK_TILE - 1) / SK_TILE;
+  return (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2 * sizeof(float);
+}
+
+template <typename T, int D>
+static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h, float* scores,
+                    float* part, const int* cu_q, const int* cu_k, int B, int HKV, int w, int ntile, float scale,
+                    int pool, hipStream_t st) {
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid(B * ntile * HKV), block(256);
+#define SNAP(G_)                                                                                                      \
+  {                                                                                                                   \
+    hipLaunchKernelGGL((snapkv_kernel<T, D, G_, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,  \
+                       sq_n, sk_n, sk_h, scores, part, cu_q, cu_k, B, HKV, w, ntile, c, pool);                         \
+    hipLaunchKernelGGL((snapkv_kernel<T, D, G_, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
+                       sq_n, sk_n, sk_h, scores, part, cu_q, cu_k, B, HKV, w, ntile, c, pool);                         \
+  }
+  switch (G) {
+    case 1: SNAP(1); break;
+    case 2: SNAP(2); break;
+    case 4: SNAP(4); break;
+    case 8: SNAP(8); break;
+    default: return CVLLM_ERR_SHAPE;
+  }
+#undef SNAP
+  return check_launch();
+}
+
+extern "C" int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                                   float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int B,
+                                   int HQ, int HKV, int D, int w, float sm_scale, int pool, int max_seqlen_k,
+                                   int dtype, void* workspace, size_t workspace_bytes, cvllm_stream_t stream) {
+  if (!q || !k || !scores || !cu_seqlens_q || !cu_seqlens_k) return CVLLM_ERR_ARG;
+  if (B <= 0 || HQ <= 0 || HKV <= 0 || max_seqlen_k <= 0 || pool <= 0) return CVLLM_ERR_ARG;
+  if (HQ % HKV != 0) return CVLLM_ERR_SHAPE;
+  const int G = HQ / HKV;
+  if (w <= 0 || w * G > SK_MAXQB * 32) return CVLLM_ERR_SHAPE;
+  if ((sq_n % 8) || (sk_n % 8) || (sk_h % 8)) return CVLLM_ERR_SHAPE;
+  if (!workspace || workspace_bytes < cvllm_snapkv_workspace_bytes(B, HKV, w, max_seqlen_k)) return CVLLM_ERR_WORKSPACE;
+  const int ntile = (max_seqlen_k + SK_TILE - 1) / SK_TILE;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == CVLLM_F16 && D == 128) return snapkv_g<F16, 128>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
+  if (dtype == CVLLM_F16 && D == 64) return snapkv_g<F16, 64>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
+  if (dtype == CVLLM_BF16 && D == 128) return snapkv_g<BF16, 128>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
+  if (dtype == CVLLM_BF16 && D == 64) return snapkv_g<BF16, 64>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
+  return CVLLM_ERR_SHAPE;
+}

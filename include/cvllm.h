@@ -95,11 +95,10 @@ int cvllm_prefill_attn(const void* q, const void* k, const void* v, int64_t sq_n
 /* ---- a6: segmented z-score -------------------------------------------------------------------
  * replaces compression/compactor.py:224-269 _zscore_per_batch_epilogue_no_window.
  * x[N,H] in place; score_dtype 0/1 = f16/bf16, 2 = f32; cu[n_segments+1] int32 row offsets.
- * Optional fused epilogue (compactor.py:586-598): x = z(x) + blend*accum (accum_dtype as
- * score_dtype, may be NULL), then rows [first,last) protected ranges <- +inf when
- * prot_first/prot_last (int32 [n_segments]) are given.  Python-slice semantics of the
- * reference's fills (quirk Q9) are reproduced by the host wrapper, which passes explicit
- * [lo,hi) row ranges: prot_ranges int32 [n_ranges,2], may be NULL.                         */
+ * Optional fused epilogue (compactor.py:586-598): x = z(x) + blend*accum (accum_dtype coded as
+ * score_dtype, accum may be NULL), then the rows of prot_ranges (int32 [n_ranges,2] = [lo,hi)
+ * row ranges, may be NULL) <- +inf.  The python-slice semantics of the reference's fills
+ * (quirk Q9) are resolved to explicit ranges by the host wrapper.                            */
 int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
                           const void* accum, int accum_dtype, float blend,
                           const int32_t* prot_ranges, int n_ranges, int total_rows,
@@ -118,23 +117,27 @@ int cvllm_chunk_attn_mass(const void* q, const void* k, int64_t sq_n, int64_t sk
  * replaces compression/compactor.py:113-221 approximate_leverage_scores (matmul + SVD path).
  * key_states[N,HKV,D] (strides s_n,s_h), PHI[D,k] row-major same dtype, chunk_cu[n_chunks+1]
  * int32 row offsets of the chunks (host-built exactly like split_into_chunks :62-110),
- * scores[N,HKV] f32 out: x_i^T (Xc^T Xc + reg I)^-1 x_i.  Chunks longer than `max_chunk_rows`
- * are rejected (CVLLM_ERR_SHAPE).                                                              */
+ * scores[N,HKV] f32 out: x_i^T (Xc^T Xc + reg I)^-1 x_i, X = K_h PHI centred per chunk, evaluated
+ * by Cholesky in fp32 (the reference takes an SVD of the 16-bit Gram matrix; same closed form).
+ * sketch_dim must be 48 (LLMConfig.leverage_sketch_size).  workspace: X in fp32.               */
+size_t cvllm_leverage_workspace_bytes(int total_tokens, int HKV, int sketch_dim);
 int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_t s_h, const void* phi,
                           float* scores, const int32_t* chunk_cu, int n_chunks, int total_tokens,
                           int HKV, int D, int sketch_dim, float regularizer, int dtype,
                           void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
-size_t cvllm_leverage_workspace_bytes(int n_chunks, int HKV, int sketch_dim);
 
 /* ---- a8: SnapKV window scores -------------------------------------------------------------------
  * replaces compression/snapkv.py:332-448 query_aware_key_scores + :39-157 + :160-276.
- * scores[Nk,HKV] f32 out; window w (<=32*?); 5-tap trailing mean clipped at 128-key tiles
- * (pinned); last w keys <- +inf; sequences with L<=w are all +inf.                 */
+ * scores[Nk,HKV] f32 out; rows = last w queries x G heads (w*G <= 256); keys [0, L-w);
+ * `pool`-tap trailing mean clipped at 128-key tiles (the reference's autotuned BLOCK_K, pinned;
+ * SURVEY P3); last w keys <- +inf; sequences with L <= w are all +inf (reference: uninitialised).
+ * No fp32 logits buffer: two passes over K with per-tile (max,sum) partials in `workspace`.     */
+size_t cvllm_snapkv_workspace_bytes(int B, int HKV, int w, int max_seqlen_k);
 int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                         float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                         int B, int HQ, int HKV, int D, int w, float sm_scale, int pool,
-                        int dtype, void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
-size_t cvllm_snapkv_workspace_bytes(int B, int HQ, int w, int max_seqlen_k);
+                        int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
+                        cvllm_stream_t stream);
 
 /* ---- a9: joint top-k selection ------------------------------------------------------------------
  * replaces compression/common.py:171-243 scores_to_retain_indices (torch.topk full sort) and the

@@ -71,6 +71,28 @@ def bench_decode(args):
                   f"{bytes_alg / us / 1e6:7.3f} TB/s algorithmic", flush=True)
 
 
+def bench_prefill(args):
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16
+    B, HQ, HKV, D, PS = args.B, 32, 8, 128, 128
+    for L in ([args.L] if args.L != 16384 or True else []):
+        N = B * L
+        q = torch.randn(N, HQ, D, device=dev, dtype=dtype)
+        k = torch.randn(N, HKV, D, device=dev, dtype=dtype)
+        v = torch.randn(N, HKV, D, device=dev, dtype=dtype)
+        kc = torch.zeros(PS, D, device=dev, dtype=dtype)
+        lens = torch.zeros(B, HKV, dtype=torch.int32, device=dev)
+        pt = torch.zeros(B + 1, HKV, 1, dtype=torch.int32, device=dev)
+        bm = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
+        cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L
+        fn = lambda: causal_sparse_varlen_with_cache(q, k, v, kc, kc, lens, pt, bm, cu, L, 0, HKV, PS)
+        us = time_fn(fn, iters=5, warmup=2)
+        flops = 4 * D * HQ * B * (L * (L + 1) / 2)
+        print(f"prefill B={B} L={L}: {us / 1e3:9.3f} ms  {flops / us / 1e6:8.1f} TFLOP/s (causal flops)", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what")
@@ -79,4 +101,4 @@ if __name__ == "__main__":
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1)
     a = ap.parse_args()
-    {"decode": bench_decode}[a.what](a)
+    {"decode": bench_decode, "prefill": bench_prefill}[a.what](a)
