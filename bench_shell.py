@@ -1,0 +1,256 @@
+"""Thin random-weight model shell + generate loop used ONLY to measure the hot path in situ.
+
+The reference's engine (scheduler, model runner, models) is out of scope; measuring the
+BASELINE.json metric (prompt+generated tokens per second of one `generate` call, scheduler.py:203-205) still
+needs *something* that produces q/k/v around the attention boundary with the real shapes and issues the calls
+in the reference's order (models/llama3.py:90-112, qwen3.py:82-104).  This file is that something:
+Llama-3.1-8B / Qwen3-8B shaped bf16 weights ~N(0, 0.02^2), dense projections through torch.matmul
+(hipBLASLt), three glue kernels (tools/shell/shell_ops.hip), the compactor_vllm_amd Attention module and
+compression hooks, a PagedKVCache, greedy sampling, and a HIP-graph decode loop.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+import sys
+from dataclasses import dataclass
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "compactor-vllm_amd"))
+
+from compactor_vllm_amd.compression import (  # noqa: E402
+    CompressionMethod,
+    apply_postrope_compression,
+    apply_prerope_compression,
+)
+from compactor_vllm_amd.kv_cache.page_table import KVAllocationStatus, PagedKVCache  # noqa: E402
+from compactor_vllm_amd.layers.attention import Attention  # noqa: E402
+from compactor_vllm_amd.utils.context import CompressionContext, get_context, set_context  # noqa: E402
+
+SHELL_DIR = os.path.join(ROOT, "tools", "shell")
+SHELL_LIB = os.path.join(SHELL_DIR, "libbench_shell.so")
+
+
+def build_shell_lib(force: bool = False) -> str:
+    src = os.path.join(SHELL_DIR, "shell_ops.hip")
+    if force or not os.path.exists(SHELL_LIB) or os.path.getmtime(src) > os.path.getmtime(SHELL_LIB):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src,
+                        "-o", SHELL_LIB], check=True)
+    return SHELL_LIB
+
+
+_shell = None
+
+
+def shell():
+    global _shell
+    if _shell is None:
+        if not os.path.exists(SHELL_LIB):
+            raise RuntimeError(f"{SHELL_LIB} missing: run __graft_entry__.build()")
+        L = ctypes.CDLL(SHELL_LIB)
+        P, I, F, L64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+        L.shell_add_rmsnorm.argtypes = [P, P, P, P, I, I, F, P]
+        L.shell_rope.argtypes = [P, L64, P, P, P, P, I, I, F, P]
+        L.shell_silu_mul.argtypes = [P, P, ctypes.c_long, I, P]
+        for f in (L.shell_add_rmsnorm, L.shell_rope, L.shell_silu_mul):
+            f.restype = None
+        _shell = L
+    return _shell
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class ShellConfig:
+    name: str = "llama-3.1-8b-shape"
+    hidden: int = 4096
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 8
+    head_dim: int = 128
+    intermediate: int = 14336
+    vocab: int = 128256
+    rope_theta: float = 500000.0
+    rms_eps: float = 1e-5
+    qk_norm: bool = False
+    max_pos: int = 131072
+
+
+LLAMA31_8B = ShellConfig()
+QWEN3_8B = ShellConfig(name="qwen3-8b-shape", layers=36, intermediate=12288, vocab=151936, rope_theta=1000000.0,
+                       rms_eps=1e-6, qk_norm=True, max_pos=40960)
+TINY = ShellConfig(name="tiny-shape", hidden=512, layers=2, heads=8, kv_heads=2, intermediate=1024, vocab=1024,
+                   max_pos=8192)
+
+
+class ModelShell:
+    def __init__(self, cfg: ShellConfig, device, max_model_len: int, max_seqs: int = 1, page_size: int = 128,
+                 seed: int = 0):
+        self.cfg, self.dev = cfg, device
+        g = torch.Generator(device=device).manual_seed(seed)
+        dt = torch.bfloat16
+
+        def w(*shape):
+            return (torch.randn(*shape, device=device, dtype=torch.float32, generator=g) * 0.02).to(dt)
+
+        H, D = cfg.hidden, cfg.head_dim
+        self.qsz, self.kvsz = cfg.heads * D, cfg.kv_heads * D
+        self.embed = w(cfg.vocab, H)
+        self.lm_head = w(cfg.vocab, H)
+        self.final_norm = torch.ones(H, device=device, dtype=dt)
+        self.layers = []
+        for _ in range(cfg.layers):
+            self.layers.append(dict(
+                wqkv=w(self.qsz + 2 * self.kvsz, H), wo=w(H, self.qsz), wgu=w(2 * cfg.intermediate, H),
+                wd=w(H, cfg.intermediate), n1=torch.ones(H, device=device, dtype=dt),
+                n2=torch.ones(H, device=device, dtype=dt),
+                qn=torch.ones(D, device=device, dtype=dt) if cfg.qk_norm else None,
+                kn=torch.ones(D, device=device, dtype=dt) if cfg.qk_norm else None,
+            ))
+        # rope table [pos, cos(64) | sin(64)] fp32 (plain theta; llama3 frequency scaling does not change cost)
+        npos = min(cfg.max_pos, max_model_len + 8)
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, device=device, dtype=torch.float32) / D))
+        ang = torch.arange(npos, device=device, dtype=torch.float32)[:, None] * inv[None, :]
+        self.rope_cs = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous()
+        # paged cache: pages for the FULL uncompressed length are reserved before prefill, like the reference
+        pages_per_head = -(-max_model_len // page_size)
+        n_pages = max_seqs * cfg.kv_heads * pages_per_head + 8
+        self.cache = PagedKVCache(cfg.layers, pages_per_head, n_pages, page_size, cfg.kv_heads, D, max_seqs + 1, dt,
+                                  device)
+        self.attn = []
+        for li in range(cfg.layers):
+            a = Attention(cfg.heads, D, 1.0 / math.sqrt(D), cfg.kv_heads)
+            a.k_cache, a.v_cache, a.page_table, a.bh_seq_lens = self.cache.layer_slices(li)
+            a.page_size = page_size
+            self.attn.append(a)
+        self.store_stream = torch.cuda.Stream(device=device)
+        self.PHI = (torch.randn(D, 48, device=device, generator=g) / math.sqrt(48)).to(dt)
+
+    # ---- one forward pass over N packed tokens (prefill) or B single tokens (decode) -----------------------
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor, last_rows: torch.Tensor | None) -> torch.Tensor:
+        cfg, S = self.cfg, shell()
+        N = tokens.numel()
+        H, D, I = cfg.hidden, cfg.head_dim, cfg.intermediate
+        ctx = get_context()
+        h = self.embed.index_select(0, tokens)
+        x = torch.empty_like(h)
+        delta = None
+        for li, L in enumerate(self.layers):
+            S.shell_add_rmsnorm(h.data_ptr(), None if delta is None else delta.data_ptr(), L["n1"].data_ptr(),
+                                x.data_ptr(), N, H, cfg.rms_eps, _st())
+            qkv = torch.matmul(x, L["wqkv"].t())
+            q_pre = qkv[:, : self.qsz].view(N, cfg.heads, D)
+            k_pre = qkv[:, self.qsz : self.qsz + self.kvsz].view(N, cfg.kv_heads, D)
+            v = qkv[:, self.qsz + self.kvsz :].view(N, cfg.kv_heads, D)  # strided view, like the reference
+            scores = None
+            compress = ctx.is_prefill and ctx.do_compression
+            if compress and not cfg.qk_norm:
+                scores = apply_prerope_compression(q_pre, k_pre, v, ctx)
+            q = torch.empty((N, cfg.heads, D), dtype=h.dtype, device=h.device)
+            k = torch.empty((N, cfg.kv_heads, D), dtype=h.dtype, device=h.device)
+            S.shell_rope(q_pre.data_ptr(), qkv.stride(0), q.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
+                         None if L["qn"] is None else L["qn"].data_ptr(), N, cfg.heads, cfg.rms_eps, _st())
+            S.shell_rope(k_pre.data_ptr(), qkv.stride(0), k.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
+                         None if L["kn"] is None else L["kn"].data_ptr(), N, cfg.kv_heads, cfg.rms_eps, _st())
+            if compress and cfg.qk_norm:
+                # Qwen3 scores the NORMED pre-RoPE keys (qwen3.py:88-94); SnapKV/NONE have no pre-RoPE phase
+                scores = apply_prerope_compression(q_pre, k_pre, v, ctx)
+            if compress:
+                scores = apply_postrope_compression(q, k, v, scores, ctx)
+            o = self.attn[li](q, k, v, scores)
+            delta = torch.matmul(o.view(N, self.qsz), L["wo"].t())
+            S.shell_add_rmsnorm(h.data_ptr(), delta.data_ptr(), L["n2"].data_ptr(), x.data_ptr(), N, H, cfg.rms_eps,
+                                _st())
+            gu = torch.matmul(x, L["wgu"].t())
+            act = torch.empty((N, I), dtype=h.dtype, device=h.device)
+            S.shell_silu_mul(gu.data_ptr(), act.data_ptr(), N, I, _st())
+            del gu
+            delta = torch.matmul(act, L["wd"].t())
+            del act
+        if last_rows is not None:
+            h = h.index_select(0, last_rows)
+            delta = delta.index_select(0, last_rows)
+        xf = torch.empty_like(h)
+        S.shell_add_rmsnorm(h.data_ptr(), delta.data_ptr(), self.final_norm.data_ptr(), xf.data_ptr(), h.shape[0], H,
+                            cfg.rms_eps, _st())
+        logits = torch.matmul(xf, self.lm_head.t())
+        return logits.argmax(dim=-1)  # temperature 0
+
+    # ---- generate: prefill (+ compression overlapped on the store stream) then HIP-graph decode ----------------
+    def generate(self, prompts: list, max_new_tokens: int, method: CompressionMethod, ratio: float,
+                 first: int = 16, last: int = 64, chunk: int = 512, use_graph: bool = True, keep_state=None):
+        dev, cfg = self.dev, self.cfg
+        B = len(prompts)
+        lens = [int(p.numel()) for p in prompts]
+        rows = []
+        for L in lens:
+            bi = self.cache.new_batch()
+            assert bi is not None
+            assert self.cache.reserve_tokens(bi, L + max_new_tokens) == KVAllocationStatus.SUCCESS
+            rows.append(bi)
+        bm = torch.tensor(rows, dtype=torch.int32, device=dev)
+        tokens = torch.cat(prompts).to(dev)
+        positions = torch.cat([torch.arange(L, device=dev, dtype=torch.int64) for L in lens])
+        cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+        do_comp = method != CompressionMethod.NONE and ratio < 1.0
+        cc = None
+        if do_comp:
+            retain = [max(int(round(ratio * (L - first - last) * cfg.kv_heads)), 1) for L in lens]  # arguments.py:109-121
+            cc = CompressionContext(
+                compression_method=method, compression_chunk_size=chunk if method == CompressionMethod.COMPACTOR else -1,
+                batch_tokens_to_retain=torch.tensor(retain, dtype=torch.int32, device=dev),
+                max_tokens_to_retain=max(lens) * cfg.kv_heads, context_lens=lens, PHI=self.PHI,
+                protected_first_tokens=[first] * B, protected_last_tokens=[last] * B)
+        set_context(is_prefill=True, do_compression=do_comp, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=max(lens),
+                    max_seqlen_k=max(lens), batch_mapping=bm, max_bh_len=0, compression_context=cc,
+                    STORE_STREAM=self.store_stream)
+        last_rows = (cu[1:] - 1).to(torch.int64)
+        tok = self.forward(tokens, positions, last_rows)
+        # H2 of SURVEY §3.1: lengths are written on the store stream; join before anything reads them
+        torch.cuda.current_stream().wait_stream(self.store_stream)
+        if do_comp:
+            for bi in rows:
+                self.cache.reclaim_pages(bi, future_reserve_tokens=max_new_tokens)
+        out_tokens = [tok]
+        pos = torch.tensor(lens, dtype=torch.int64, device=dev)
+        set_context(is_prefill=False, batch_mapping=bm)
+        n_dec = max_new_tokens - 1
+        if n_dec > 0:
+            if use_graph:
+                static_tok, static_pos = tok.clone(), pos.clone()
+                for _ in range(2):  # warm-up outside capture (workspace allocation, lazy inits)
+                    if n_dec <= 0:
+                        break
+                    t = self.forward(static_tok, static_pos, None)
+                    static_tok.copy_(t)
+                    static_pos.add_(1)
+                    out_tokens.append(t.clone())
+                    n_dec -= 1
+                if n_dec > 0:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        t = self.forward(static_tok, static_pos, None)
+                        static_tok.copy_(t)
+                        static_pos.add_(1)
+                    for _ in range(n_dec):
+                        graph.replay()
+                        out_tokens.append(static_tok.clone())
+            else:
+                for _ in range(n_dec):
+                    tok = self.forward(tok, pos, None)
+                    pos = pos + 1
+                    out_tokens.append(tok)
+        torch.cuda.synchronize()
+        result = torch.stack(out_tokens, dim=1)
+        if keep_state is not None:
+            keep_state.update(rows=rows, bm=bm, lens=lens)
+        else:
+            for bi in rows:
+                self.cache.free_batch(bi)
+        return result

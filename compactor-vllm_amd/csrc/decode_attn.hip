@@ -620,6 +620,7 @@ static int launch_decode_v(const void* q, const void* kc, const void* vc, void* 
   return check_launch();
 }
 
+static hipEvent_t g_evt_start = nullptr, g_evt_stop = nullptr;  // bench.py roofline leg (stage-1 only)
 static int g_decode_nt = 1;  // K/V are read once per step: non-temporal LDS-DMA measured 5-8% faster
 static int g_decode_nocompute = 0;
 
@@ -656,8 +657,10 @@ static int launch_decode_ring_nt(const void* q, const void* kc, const void* vc, 
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done[1] = true;
   }
+  if (g_evt_start) (void)hipEventRecord(g_evt_start, st);
   hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
                      (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+  if (g_evt_stop) (void)hipEventRecord(g_evt_stop, st);
   hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
                      (uint16_t*)out, HQ, S);
   return check_launch();
@@ -755,6 +758,12 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
     return dispatch_d<BF16>(D, G, q, k_cache, v_cache, out, seq_lens_bh, page_table, batch_mapping,
                             (float*)workspace, B, HKV, page_size, n_logical_pages_max, sm_scale, n_splits, st);
   return CVLLM_ERR_SHAPE;
+}
+
+// bench.py: HIP events recorded immediately before / after the stage-1 launch on the launch stream (NULL = off)
+extern "C" void cvllm_debug_set_decode_events(void* start, void* stop) {
+  g_evt_start = (hipEvent_t)start;
+  g_evt_stop = (hipEvent_t)stop;
 }
 
 extern "C" void cvllm_debug_set_decode_variant(int v) { g_decode_variant = v & 0xff; g_decode_nt = ((v >> 8) & 1) ^ 1; g_decode_nocompute = (v >> 9) & 1; }

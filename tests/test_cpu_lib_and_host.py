@@ -1,0 +1,143 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/cvllm.h declares (no compute calls
+without a GPU), host-side logic (chunk splitting, protected ranges, split planning, page allocator), and the
+product path's refusal to run without a GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cvllm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvllm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from compactor_vllm_amd import _lib
+
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    L = _lib.lib()
+    for s in syms:
+        assert hasattr(L, s), f"libcvllm_hip.so does not export {s}"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table out of sync with include/cvllm.h"
+    assert _lib.missing_symbols() == []
+    assert L.cvllm_version() >= 100
+    assert L.cvllm_error_string(-3).decode().startswith("workspace")
+
+
+def test_host_only_entry_points():
+    from compactor_vllm_amd import _lib
+
+    L = _lib.lib()
+    assert L.cvllm_decode_workspace_bytes(2, 32, 128, 8) == (2 * 8 * 32 * 128 + 2 * 8 * 32) * 4
+    assert L.cvllm_decode_workspace_bytes(0, 32, 128, 8) == 0
+    assert L.cvllm_select_workspace_bytes(3, 8, 1000) == 3 * 8 * 4
+    assert L.cvllm_leverage_workspace_bytes(100, 8, 48) == 100 * 8 * 48 * 4
+    assert L.cvllm_rank_workspace_bytes(2, 8, 512) > 4 * 2 * 512 * 8 * 4
+    # argument validation happens before any launch: null pointers -> CVLLM_ERR_ARG, no GPU touched
+    assert L.cvllm_decode_attn(None, None, None, None, None, None, None, None, 0, 1, 8, 2, 128, 128, 4, 1.0, 1, 0,
+                               None) == -1
+    assert L.cvllm_store_all_kv(None, None, 0, 0, 0, 0, None, None, None, None, None, None, 1, 1, 2, 128, 128, 4, 0,
+                                None) == -1
+
+
+def test_num_splits_heuristic_known_answers():
+    """Values of the reference's num_splits_heuristic (sparse_decode_kernel.py:169-192), num_sms = 256
+    (SURVEY App. C occupancy note) and H100-like 132."""
+    from compactor_vllm_amd.attention.sparse_decode_kernel import num_splits_heuristic, plan_internal_splits
+
+    assert num_splits_heuristic(8, 16384, 256, 12) == 9
+    assert num_splits_heuristic(8, 32768, 256, 12) == 9
+    assert num_splits_heuristic(64, 65536, 256, 12) == 3
+    assert num_splits_heuristic(205, 65536, 256, 12) == 1
+    assert num_splits_heuristic(8, 1024, 256, 12) == 1
+    assert num_splits_heuristic(1, 65536, 132, 128) == 96
+    # internal plan: one workgroup per CU, >= 256 rows per split, honours the caller's hint as a lower bound
+    assert plan_internal_splits(8, 40960, None) == 32
+    assert plan_internal_splits(8, 40960, 9) == 32
+    assert plan_internal_splits(512, 40960, None) == 1
+    assert plan_internal_splits(8, 512, None) == 2
+    assert plan_internal_splits(8, 512, 12) == 12
+
+
+def test_split_into_chunks_matches_reference_docstring():
+    from compactor_vllm_amd.compression.compactor import split_into_chunks
+
+    assert split_into_chunks([257, 127], 128) == ([256, 1, 127], [128, 128, 1, 127])  # compactor.py:84-87
+    assert split_into_chunks([512, 5], 512) == ([512, 5], [512, 5])
+    assert split_into_chunks([0, 3], 4) == ([3], [3])
+
+
+def test_protected_ranges_python_slice_semantics():
+    from compactor_vllm_amd.compression.compactor import _protected_ranges
+    from oracle import ref_cpu as O
+
+    lens, first, last = [40, 200, 20], [16, 16, 16], [64, 64, 64]
+    N = sum(lens)
+    ref = torch.zeros(N, 2)
+    O.fill_protected(ref, lens, first, last)
+    mine = torch.zeros(N, 2)
+    for lo, hi in _protected_ranges(lens, first, last, N):
+        mine[lo:hi] = float("inf")
+    assert torch.equal(ref, mine)
+
+
+def test_retain_count_bankers_round():
+    from oracle import ref_cpu as O
+
+    assert O.retain_count(0.5, 32768, 16, 64, 8) == 130752
+    assert O.retain_count(1.0, 50, 16, 64, 8) == 1  # quirk Q2: first+last >= L
+    assert O.retain_count(0.5, 81, 0, 0, 1) == 40   # round(40.5) = 40 (banker's)
+
+
+def test_paged_kv_cache_allocator_cpu():
+    from compactor_vllm_amd.kv_cache.page_table import KVAllocationStatus, PagedKVCache
+
+    c = PagedKVCache(num_layers=2, max_logical_pages_per_head=4, num_pages=20, page_size=128, H_kv=2, head_dim=64,
+                     max_num_batches=3, dtype=torch.float16, device="cpu")
+    assert c.kv_cache.shape == (2, 2, 20 * 128, 64) and c.page_table.shape == (2, 4, 2, 4)
+    b = c.new_batch()
+    assert b == 1  # row 0 is RESERVED_BATCH
+    assert c.reserve_tokens(b, 300) == KVAllocationStatus.SUCCESS
+    assert (c.bh_num_pages[:, b] == 3).all()
+    assert sorted(c.page_table[0, b].reshape(-1)[[0, 1, 2, 4, 5, 6]].tolist()) == [0, 1, 2, 3, 4, 5]
+    assert c.reserve_tokens(b, 300) == KVAllocationStatus.SUCCESS  # already covered
+    assert c.reserve_tokens(b, 600) == KVAllocationStatus.EXCEEDS_MAX_SEQUENCE_LENGTH
+    b2 = c.new_batch()
+    assert c.reserve_tokens(b2, 512) == KVAllocationStatus.SUCCESS
+    b3 = c.new_batch()
+    assert c.reserve_tokens(b3, 512) == KVAllocationStatus.EXCEEDS_CURRENTLY_AVAILABLE_PAGES
+    c.bh_seq_lens[:, b] = 100  # pretend compression kept 100 rows per head
+    freed = c.reclaim_pages(b, future_reserve_tokens=20)
+    assert freed == 2 * 2 * 2 * (128 * 64 * 2) * 2  # 2 layers x 2 heads x 2 pages, K+V
+    assert (c.bh_num_pages[:, b] == 1).all()
+    c.free_batch(b)
+    assert len(c.free_pages[0]) == 20 - 8
+    k, v, pt, bh = c.layer_slices(1)
+    assert k.data_ptr() == c.kv_cache[0, 1].data_ptr() and bh.shape == (4, 2)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from compactor_vllm_amd.attention.sparse_decode_kernel import head_sparse_decode_attention
+
+    q = torch.zeros(1, 8, 128, dtype=torch.float16)
+    kc = torch.zeros(128, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        head_sparse_decode_attention(q, kc, kc, torch.ones(1, 2, dtype=torch.int32),
+                                     torch.zeros(2, 2, 1, dtype=torch.int32), torch.ones(1, dtype=torch.int32), 2, 128)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "compactor-vllm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# the oracle", ""), f"{f} mentions the oracle"

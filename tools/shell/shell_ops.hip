@@ -1,0 +1,126 @@
+// Glue kernels of the benchmark's random-weight model shell (RMSNorm, RoPE, SiLU*mul).  NOT part of the
+// compactor hot path and not part of libcvllm_hip.so: bench.py needs a Llama/Qwen3-shaped producer of
+// q/k/v around the attention boundary to measure tokens/s; these keep that producer from
+// being dominated by unfused elementwise passes.  bf16 in/out, fp32 math.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f2bf(float x) {
+  __bf16 h = (__bf16)x;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// h[n,:] += delta[n,:] (if delta), y[n,:] = rmsnorm(h[n,:]) * w ; one 256-thread block per row, C % 8 == 0
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(uint16_t* __restrict__ h, const uint16_t* __restrict__ delta,
+                                                          const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
+                                                          int C, float eps) {
+  __shared__ float s_part[4];
+  const size_t row = blockIdx.x;
+  uint16_t* hr = h + row * C;
+  const uint16_t* dr = delta ? delta + row * C : nullptr;
+  float ss = 0.f;
+  for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+    uint4 hv = *reinterpret_cast<const uint4*>(hr + c);
+    uint16_t* hp = reinterpret_cast<uint16_t*>(&hv);
+    if (dr) {
+      uint4 dv = *reinterpret_cast<const uint4*>(dr + c);
+      const uint16_t* dp = reinterpret_cast<const uint16_t*>(&dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hp[j] = f2bf(bf2f(hp[j]) + bf2f(dp[j]));
+      *reinterpret_cast<uint4*>(hr + c) = hv;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf2f(hp[j]);
+      ss += f * f;
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float inv = rsqrtf((s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)C + eps);
+  for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+    uint4 hv = *reinterpret_cast<const uint4*>(hr + c);
+    uint4 wv = *reinterpret_cast<const uint4*>(w + c);
+    const uint16_t* hp = reinterpret_cast<const uint16_t*>(&hv);
+    const uint16_t* wp = reinterpret_cast<const uint16_t*>(&wv);
+    uint4 ov;
+    uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) op[j] = f2bf(bf2f(hp[j]) * inv * bf2f(wp[j]));
+    *reinterpret_cast<uint4*>(y + row * C + c) = ov;
+  }
+}
+
+// neox RoPE (+ optional per-head RMSNorm before it, Qwen3 q/k-norm): src rows [N, H, 128] with token stride
+// s_n -> dst contiguous [N, H, 128].  one wave per (token, head): lane l handles dims l and l+64.
+__global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ src, int64_t s_n,
+                                                   uint16_t* __restrict__ dst, const int64_t* __restrict__ pos,
+                                                   const float* __restrict__ cs, const uint16_t* __restrict__ nw,
+                                                   int N, int H, float eps) {
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long)N * H) return;
+  const int n = (int)(wid / H), hh = (int)(wid % H), l = threadIdx.x & 63;
+  const uint16_t* sp = src + (size_t)n * s_n + (size_t)hh * 128;
+  float a = bf2f(sp[l]), b = bf2f(sp[l + 64]);
+  if (nw) {
+    const float inv = rsqrtf(wave_sum(a * a + b * b) / 128.f + eps);
+    a = bf2f(f2bf(a * inv * bf2f(nw[l])));
+    b = bf2f(f2bf(b * inv * bf2f(nw[l + 64])));
+  }
+  const float* t = cs + (size_t)pos[n] * 128;  // [cos(64) | sin(64)]
+  const float c = t[l], s = t[64 + l];
+  uint16_t* dp = dst + ((size_t)n * H + hh) * 128;
+  dp[l] = f2bf(a * c - b * s);
+  dp[l + 64] = f2bf(b * c + a * s);
+}
+
+// out[n, i] = silu(gu[n, i]) * gu[n, I + i]
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out,
+                                                       long total, int I) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 8; e < total; e += (long)gridDim.x * 256 * 8) {
+    const long n = e / I;
+    const int i = (int)(e % I);
+    uint4 gv = *reinterpret_cast<const uint4*>(gu + n * 2 * I + i);
+    uint4 uv = *reinterpret_cast<const uint4*>(gu + n * 2 * I + I + i);
+    const uint16_t* gp = reinterpret_cast<const uint16_t*>(&gv);
+    const uint16_t* up = reinterpret_cast<const uint16_t*>(&uv);
+    uint4 ov;
+    uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float g = bf2f(gp[j]);
+      op[j] = f2bf(g / (1.f + __expf(-g)) * bf2f(up[j]));
+    }
+    *reinterpret_cast<uint4*>(out + n * I + i) = ov;
+  }
+}
+
+extern "C" void shell_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int N, int C, float eps,
+                                  void* stream) {
+  if (N > 0)
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (uint16_t*)h,
+                       (const uint16_t*)delta, (const uint16_t*)w, (uint16_t*)y, C, eps);
+}
+extern "C" void shell_rope(const void* src, int64_t s_n, void* dst, const void* pos, const void* cs, const void* nw,
+                           int N, int H, float eps, void* stream) {
+  const long waves = (long)N * H;
+  if (waves > 0)
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)src, s_n, (uint16_t*)dst, (const int64_t*)pos, (const float*)cs,
+                       (const uint16_t*)nw, N, H, eps);
+}
+extern "C" void shell_silu_mul(const void* gu, void* out, long N, int I, void* stream) {
+  const long total = N * I;
+  long blocks = (total / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (total > 0)
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)gu, (uint16_t*)out, total, I);
+}
