@@ -54,7 +54,7 @@ def shell():
         L = ctypes.CDLL(SHELL_LIB)
         P, I, F, L64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
         L.shell_add_rmsnorm.argtypes = [P, P, P, P, I, I, F, P]
-        L.shell_rope.argtypes = [P, L64, P, P, P, P, I, I, F, P]
+        L.shell_rope.argtypes = [P, L64, P, P, P, P, P, I, I, I, F, P]
         L.shell_silu_mul.argtypes = [P, P, ctypes.c_long, I, P]
         for f in (L.shell_add_rmsnorm, L.shell_rope, L.shell_silu_mul):
             f.restype = None
@@ -152,15 +152,18 @@ class ModelShell:
             compress = ctx.is_prefill and ctx.do_compression
             if compress and not cfg.qk_norm:
                 scores = apply_prerope_compression(q_pre, k_pre, v, ctx)
-            q = torch.empty((N, cfg.heads, D), dtype=h.dtype, device=h.device)
-            k = torch.empty((N, cfg.kv_heads, D), dtype=h.dtype, device=h.device)
-            S.shell_rope(q_pre.data_ptr(), qkv.stride(0), q.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
-                         None if L["qn"] is None else L["qn"].data_ptr(), N, cfg.heads, cfg.rms_eps, _st())
-            S.shell_rope(k_pre.data_ptr(), qkv.stride(0), k.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
-                         None if L["kn"] is None else L["kn"].data_ptr(), N, cfg.kv_heads, cfg.rms_eps, _st())
-            if compress and cfg.qk_norm:
-                # Qwen3 scores the NORMED pre-RoPE keys (qwen3.py:88-94); SnapKV/NONE have no pre-RoPE phase
-                scores = apply_prerope_compression(q_pre, k_pre, v, ctx)
+            # RoPE (+ Qwen3 q/k-norm) of q and k in ONE launch into a fresh buffer: the pre-RoPE keys stay intact
+            # for the store-stream scoring; q / k below are strided views of it (the kernels take token strides)
+            qk = torch.empty((N, cfg.heads + cfg.kv_heads, D), dtype=h.dtype, device=h.device)
+            S.shell_rope(qkv.data_ptr(), qkv.stride(0), qk.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
+                         None if L["qn"] is None else L["qn"].data_ptr(),
+                         None if L["kn"] is None else L["kn"].data_ptr(), N, cfg.heads + cfg.kv_heads, cfg.heads,
+                         cfg.rms_eps, _st())
+            q = qk[:, : cfg.heads]
+            k = qk[:, cfg.heads :]
+            if compress and cfg.qk_norm and ctx.compression_context.compression_method == CompressionMethod.COMPACTOR:
+                # Qwen3 scores the NORMED pre-RoPE keys (qwen3.py:88-94); this shell fuses the norm into RoPE
+                raise NotImplementedError("shell: Compactor pre-RoPE scoring with q/k-norm needs an un-fused norm pass")
             if compress:
                 scores = apply_postrope_compression(q, k, v, scores, ctx)
             o = self.attn[li](q, k, v, scores)

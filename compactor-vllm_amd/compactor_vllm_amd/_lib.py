@@ -24,6 +24,8 @@ SIGNATURES = {
     "cvllm_error_string": (c_char_p, [_I]),
     "cvllm_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "cvllm_decode_attn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cvllm_decode_append_attn": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I,
+                                      _I, _F, _I, _I, _I, _P]),
     "cvllm_num_splits": (_I, [_I, _I, _I, _I]),
     "cvllm_store_decode_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvllm_store_all_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

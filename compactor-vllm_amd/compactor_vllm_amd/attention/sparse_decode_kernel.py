@@ -107,6 +107,49 @@ def head_sparse_decode_attention(
     return out
 
 
+def fused_decode_step(
+    q: torch.Tensor,  # [B, HQ, D]
+    key: torch.Tensor,  # [B, HKV, D] new token
+    value: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    bh_seq_lens_layer: torch.Tensor,  # [Bmax+1, HKV] int32, the layer's table, UPDATED in place
+    page_table: torch.Tensor,
+    batch_mapping: torch.Tensor,  # [B] int32
+    HKV: int,
+    PAGE_SIZE: int,
+    sm_scale: float = None,
+    key_split: int = None,
+    reserved_batch: int = 0,
+):
+    """decode_store_kv + head_sparse_decode_attention + length write-back of the reference's decode branch
+    (layers/attention.py:127-160) in one C-ABI call that works directly on the layer's length table."""
+    _lib.require_cuda(q, key, value, k_cache, v_cache, bh_seq_lens_layer, page_table, batch_mapping)
+    B, HQ, D = q.shape
+    assert key.shape == (B, HKV, D) and value.shape == (B, HKV, D)
+    assert q.is_contiguous() and key.stride(-1) == 1 and value.stride(-1) == 1
+    assert PAGE_SIZE % 32 == 0 and HQ % HKV == 0
+    assert bh_seq_lens_layer.is_contiguous() and bh_seq_lens_layer.dtype == torch.int32
+    assert batch_mapping.dtype == torch.int32 and page_table.is_contiguous() and page_table.dtype == torch.int32
+    n_lp = page_table.shape[-1]
+    sm_scale = 1 / math.sqrt(D) if sm_scale is None else sm_scale
+    n_splits = plan_internal_splits(B * HKV, n_lp * PAGE_SIZE, key_split)
+    L = _lib.lib()
+    out = torch.empty_like(q)
+    ws, ws_bytes = None, 0
+    if n_splits > 1:
+        ws_bytes = L.cvllm_decode_workspace_bytes(B, HQ, D, n_splits)
+        ws = _workspace(q.device, ws_bytes)
+    st = L.cvllm_decode_append_attn(
+        q.data_ptr(), key.data_ptr(), value.data_ptr(), key.stride(0), key.stride(1), value.stride(0), value.stride(1),
+        k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), bh_seq_lens_layer.data_ptr(), page_table.data_ptr(),
+        batch_mapping.data_ptr(), _lib.ptr(ws), ws_bytes, B, HQ, HKV, D, PAGE_SIZE, n_lp, float(sm_scale), n_splits,
+        int(reserved_batch), _lib.dtype_code(q.dtype), _lib.stream(),
+    )
+    _lib.check(st, "cvllm_decode_append_attn")
+    return out
+
+
 @functools.lru_cache(maxsize=128)
 def num_splits_heuristic(total_mblocks: int, max_seq_len: int, num_sms: int, max_splits: int) -> int:
     """Reference heuristic (sparse_decode_kernel.py:169-192), evaluated by the C ABI's host

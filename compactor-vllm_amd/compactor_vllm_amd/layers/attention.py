@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from ..attention.sparse_decode_kernel import head_sparse_decode_attention
+from ..attention.sparse_decode_kernel import fused_decode_step, head_sparse_decode_attention
 from ..attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
 from ..compression.common import extract_and_store_top_kv
 from ..config.engine_config import AttentionBackend
@@ -40,10 +40,19 @@ class Attention(nn.Module):
         self.page_table: Optional[torch.Tensor] = None
         self.bh_seq_lens: Optional[torch.Tensor] = None
         self.page_size: Optional[int] = None
+        self.fused_decode: bool = True  # False = the reference's four-call decode sequence
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scores: Optional[torch.Tensor] = None):
         context: Context = get_context()
         batch_mapping = context.batch_mapping
+        if not context.is_prefill and self.fused_decode and self.bh_seq_lens is not None:
+            # store-then-attend on the layer's own length table: one C-ABI call instead of
+            # index_select + decode_store_kv + attention + index_copy_ (same results, 3 fewer launches)
+            assert self.k_cache is not None, "KV Cache must be initialized for decoding"
+            return fused_decode_step(
+                q, k, v, self.k_cache, self.v_cache, self.bh_seq_lens, self.page_table, batch_mapping,
+                int(self.num_kv_heads), self.page_size, self.scale, key_split=context.key_split,
+            )
         seq_lens = (
             None if self.bh_seq_lens is None else self.bh_seq_lens.index_select(0, batch_mapping).contiguous()
         )

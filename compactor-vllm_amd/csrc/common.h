@@ -89,6 +89,12 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
   return v;
 }
 
+// store_kv.hip: decode append with optional indexing of bh_lens by the TRUE batch row (fused decode step)
+int store_decode_kv_impl(const void* key, const void* value, int64_t sk_b, int64_t sk_h, int64_t sv_b, int64_t sv_h,
+                         const int32_t* batch_mapping, int32_t* bh_lens, const int32_t* page_table, void* k_cache,
+                         void* v_cache, int B, int HKV, int D, int page_size, int n_logical_pages_max,
+                         int reserved_batch, int dtype, int lens_by_row, cvllm_stream_t stream);
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? CVLLM_OK : CVLLM_ERR_LAUNCH; }
 
 }  // namespace cvllm

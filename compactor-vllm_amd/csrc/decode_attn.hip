@@ -19,6 +19,7 @@
 namespace cvllm {
 
 constexpr int DEC_NW = 4;        // waves per workgroup
+static int g_lens_by_row = 0;    // set only inside cvllm_decode_append_attn (host side; launches are single-threaded)
 constexpr int DEC_PGCACHE = 512; // page ids cached in LDS per split
 
 template <int LPR>
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(DEC_NW * 64, MINW) void decode_stage1_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
     const int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
-    int HKV, int PS, int NLP, int S, float scale) {
+    int HKV, int PS, int NLP, int S, float scale, int lens_by_row) {
   constexpr int LPR = D / 8;          // lanes per row
   constexpr int RPL = 64 / LPR;       // rows per wave-load
   constexpr int UR = RPL * DEC_NL;    // rows per unit
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(DEC_NW * 64, MINW) void decode_stage1_kernel(
   const int h = bh % HKV;
   const int b = bh / HKV;
   const int HQ = HKV * HQ_G;
-  const int L = seq_lens[bh];
+  // lens_by_row: seq_lens is the layer's full [Bmax+1, HKV] table indexed by the TRUE batch row (fused decode)
+  const int L = seq_lens[lens_by_row ? bmap[b] * HKV + h : bh];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(NW * 64) void decode_stage1_ring_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
     const int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
-    int HKV, int PS, int NLP, int S, float scale) {
+    int HKV, int PS, int NLP, int S, float scale, int lens_by_row) {
   constexpr int LPR = D / 8;
   constexpr int RPL = 64 / LPR;
   constexpr int UR = RPL * NL;
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(NW * 64) void decode_stage1_ring_kernel(
   const int h = bh % HKV;
   const int b = bh / HKV;
   const int HQ = HKV * G;
-  const int L = seq_lens[bh];
+  // lens_by_row: seq_lens is the layer's full [Bmax+1, HKV] table indexed by the TRUE batch row (fused decode)
+  const int L = seq_lens[lens_by_row ? bmap[b] * HKV + h : bh];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -609,12 +612,12 @@ static int launch_decode_v(const void* q, const void* kc, const void* vc, void* 
   if (S == 1) {
     hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, true, NL, MINW>), grid, block, 0, st, (const uint16_t*)q,
                        (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
-                       page_table, bmap, HKV, PS, NLP, S, scale);
+                       page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
     return check_launch();
   }
   hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, false, NL, MINW>), grid, block, 0, st, (const uint16_t*)q,
                      (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
-                     page_table, bmap, HKV, PS, NLP, S, scale);
+                     page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
   hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
                      (uint16_t*)out, HQ, S);
   return check_launch();
@@ -642,14 +645,14 @@ static int launch_decode_ring_nt(const void* q, const void* kc, const void* vc, 
       attr_done[0] = true;
     }
     hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
-                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
     return check_launch();
   }
   if (g_decode_nocompute) {
     auto kern = decode_stage1_ring_kernel<T, D, G, false, NW, NL, R, NT, true>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
-                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
     return check_launch();
   }
   auto kern = decode_stage1_ring_kernel<T, D, G, false, NW, NL, R, NT>;
@@ -659,7 +662,7 @@ static int launch_decode_ring_nt(const void* q, const void* kc, const void* vc, 
   }
   if (g_evt_start) (void)hipEventRecord(g_evt_start, st);
   hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
-                     (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale);
+                     (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
   if (g_evt_stop) (void)hipEventRecord(g_evt_stop, st);
   hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
                      (uint16_t*)out, HQ, S);
@@ -758,6 +761,27 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
     return dispatch_d<BF16>(D, G, q, k_cache, v_cache, out, seq_lens_bh, page_table, batch_mapping,
                             (float*)workspace, B, HKV, page_size, n_logical_pages_max, sm_scale, n_splits, st);
   return CVLLM_ERR_SHAPE;
+}
+
+// Fused decode step of the boundary orchestrator (cv/layers/attention.py:127-160 decode branch): append the new
+// K/V row of every (b,h) at bh_seq_lens[batch_mapping[b], h] (in place, RESERVED rows skipped), then attend.
+// bh_seq_lens is the LAYER's full [Bmax+1, HKV] table: no index_select / index_copy round trip on the host side.
+extern "C" int cvllm_decode_append_attn(const void* q, const void* key, const void* value, int64_t sk_b, int64_t sk_h,
+                                        int64_t sv_b, int64_t sv_h, void* k_cache, void* v_cache, void* out,
+                                        int32_t* bh_seq_lens, const int32_t* page_table,
+                                        const int32_t* batch_mapping, void* workspace, size_t workspace_bytes, int B,
+                                        int HQ, int HKV, int D, int page_size, int n_logical_pages_max, float sm_scale,
+                                        int n_splits, int reserved_batch, int dtype, cvllm_stream_t stream) {
+  if (!key || !value || !bh_seq_lens) return CVLLM_ERR_ARG;
+  int st = cvllm::store_decode_kv_impl(key, value, sk_b, sk_h, sv_b, sv_h, batch_mapping, bh_seq_lens, page_table,
+                                       k_cache, v_cache, B, HKV, D, page_size, n_logical_pages_max, reserved_batch,
+                                       dtype, /*lens_by_row=*/1, stream);
+  if (st != CVLLM_OK) return st;
+  g_lens_by_row = 1;
+  st = cvllm_decode_attn(q, k_cache, v_cache, out, bh_seq_lens, page_table, batch_mapping, workspace, workspace_bytes,
+                         B, HQ, HKV, D, page_size, n_logical_pages_max, sm_scale, n_splits, dtype, stream);
+  g_lens_by_row = 0;
+  return st;
 }
 
 // bench.py: HIP events recorded immediately before / after the stage-1 launch on the launch stream (NULL = off)

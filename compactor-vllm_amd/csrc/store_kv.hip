@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void decode_store_kernel(
     const uint16_t* __restrict__ key, const uint16_t* __restrict__ value, int64_t sk_b, int64_t sk_h,
     int64_t sv_b, int64_t sv_h, const int* __restrict__ bmap, int* __restrict__ bh_lens,
     const int* __restrict__ page_table, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int BH, int HKV,
-    int PS, int NLP, int reserved) {
+    int PS, int NLP, int reserved, int lens_by_row) {
   constexpr int LPR = D / 8;
   const int row = (blockIdx.x * 256 + threadIdx.x) / LPR;  // (b,h) pair
   const int dl = threadIdx.x % LPR;
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void decode_store_kernel(
   const int b = row / HKV, h = row % HKV;
   const int bt = bmap[b];
   if (bt == reserved) return;  // padding row of a captured decode batch (store_kv_cache.py:395-397)
-  const int L = bh_lens[row];
+  const int lrow = lens_by_row ? bt * HKV + h : row;  // fused decode: the layer's full table, true batch row
+  const int L = bh_lens[lrow];
   const int pg = page_table[((size_t)bt * HKV + h) * NLP + L / PS];
   const size_t dst = ((size_t)pg * PS + L % PS) * D + dl * 8;
   const uint4 kv = *reinterpret_cast<const uint4*>(key + b * sk_b + h * sk_h + dl * 8);
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void decode_store_kernel(
   *reinterpret_cast<uint4*>(kc + dst) = kv;
   *reinterpret_cast<uint4*>(vc + dst) = vv;
   // every lane of the row has read L before any lane of the same wave stores it (same instruction stream)
-  if (dl == 0) bh_lens[row] = L + 1;
+  if (dl == 0) bh_lens[lrow] = L + 1;
 }
 
 // ---- a3: store every new row ------------------------------------------------------------------------
@@ -224,11 +225,11 @@ using namespace cvllm;
     default: return CVLLM_ERR_SHAPE;    \
   }
 
-extern "C" int cvllm_store_decode_kv(const void* key, const void* value, int64_t sk_b, int64_t sk_h,
-                                     int64_t sv_b, int64_t sv_h, const int32_t* batch_mapping, int32_t* bh_lens,
-                                     const int32_t* page_table, void* k_cache, void* v_cache, int B, int HKV,
-                                     int D, int page_size, int n_logical_pages_max, int reserved_batch,
-                                     int dtype, cvllm_stream_t stream) {
+int cvllm::store_decode_kv_impl(const void* key, const void* value, int64_t sk_b, int64_t sk_h, int64_t sv_b,
+                                int64_t sv_h, const int32_t* batch_mapping, int32_t* bh_lens,
+                                const int32_t* page_table, void* k_cache, void* v_cache, int B, int HKV, int D,
+                                int page_size, int n_logical_pages_max, int reserved_batch, int dtype,
+                                int lens_by_row, cvllm_stream_t stream) {
   if (!key || !value || !batch_mapping || !bh_lens || !page_table || !k_cache || !v_cache) return CVLLM_ERR_ARG;
   if (B <= 0 || HKV <= 0 || page_size <= 0 || n_logical_pages_max <= 0) return CVLLM_ERR_ARG;
   if (dtype != CVLLM_F16 && dtype != CVLLM_BF16) return CVLLM_ERR_SHAPE;
@@ -239,9 +240,19 @@ extern "C" int cvllm_store_decode_kv(const void* key, const void* value, int64_t
     hipLaunchKernelGGL((decode_store_kernel<DD>), dim3((BH + rows_per_block - 1) / rows_per_block), dim3(256), 0,
                        st, (const uint16_t*)key, (const uint16_t*)value, sk_b, sk_h, sv_b, sv_h, batch_mapping,
                        bh_lens, page_table, (uint16_t*)k_cache, (uint16_t*)v_cache, BH, HKV, page_size,
-                       n_logical_pages_max, reserved_batch);
+                       n_logical_pages_max, reserved_batch, lens_by_row);
   });
   return check_launch();
+}
+
+extern "C" int cvllm_store_decode_kv(const void* key, const void* value, int64_t sk_b, int64_t sk_h,
+                                     int64_t sv_b, int64_t sv_h, const int32_t* batch_mapping, int32_t* bh_lens,
+                                     const int32_t* page_table, void* k_cache, void* v_cache, int B, int HKV,
+                                     int D, int page_size, int n_logical_pages_max, int reserved_batch,
+                                     int dtype, cvllm_stream_t stream) {
+  return cvllm::store_decode_kv_impl(key, value, sk_b, sk_h, sv_b, sv_h, batch_mapping, bh_lens, page_table, k_cache,
+                                     v_cache, B, HKV, D, page_size, n_logical_pages_max, reserved_batch, dtype, 0,
+                                     stream);
 }
 
 extern "C" int cvllm_store_all_kv(const void* new_keys, const void* new_values, int64_t sk_n, int64_t sk_h,

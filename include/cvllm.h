@@ -55,6 +55,19 @@ int cvllm_decode_attn(const void* q, const void* k_cache, const void* v_cache, v
                       int B, int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
                       float sm_scale, int n_splits, int dtype, cvllm_stream_t stream);
 
+/* Fused decode step of the boundary orchestrator: replaces the decode branch of layers/attention.py:127-160
+ * (index_select of the lengths, decode_store_kv, head_sparse_decode_attention, index_copy_ back) in one call.
+ * bh_seq_lens is the LAYER's full [Bmax+1,HKV] table (indexed by batch_mapping[b]), updated in place;
+ * key/value [B,HKV,D] are the new token's rows.  Rows with batch_mapping[b]==reserved_batch are not
+ * stored and attend to nothing (zeros).  HIP-graph capture safe.                                 */
+int cvllm_decode_append_attn(const void* q, const void* key, const void* value, int64_t sk_b,
+                             int64_t sk_h, int64_t sv_b, int64_t sv_h, void* k_cache, void* v_cache,
+                             void* out, int32_t* bh_seq_lens, const int32_t* page_table,
+                             const int32_t* batch_mapping, void* workspace, size_t workspace_bytes,
+                             int B, int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
+                             float sm_scale, int n_splits, int reserved_batch, int dtype,
+                             cvllm_stream_t stream);
+
 /* replaces attention/sparse_decode_kernel.py:169-192 num_splits_heuristic (host, same results) */
 int cvllm_num_splits(int total_mblocks, int max_seq_len, int num_sms, int max_splits);
 

@@ -265,3 +265,39 @@ def test_ranked_store_golden(dev, name):
                 a = sorted(map(tuple, cache[rows].float().tolist()))
                 r = sorted(map(tuple, new[src, h].float().tolist()))
                 assert a == r
+
+
+def test_fused_decode_step_equals_four_call_sequence(dev):
+    """cvllm_decode_append_attn == index_select + decode_store_kv + decode attention + index_copy_, incl. a
+    RESERVED_BATCH padding row (skipped by the store, attends to nothing)."""
+    from compactor_vllm_amd.attention.sparse_decode_kernel import fused_decode_step, head_sparse_decode_attention
+    from compactor_vllm_amd.kv_cache.store_kv_cache import decode_store_kv
+
+    dtype, B, HQ, HKV, D, PS = torch.bfloat16, 4, 32, 8, 128, 128
+    g = torch.Generator().manual_seed(9)
+    lens = torch.randint(0, 700, (B, HKV), generator=g, dtype=torch.int32)
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens + 1, dtype, seed=3, bmax_extra=2)
+    bm[2] = 0  # RESERVED padding row
+    table = torch.zeros(pt.shape[0], HKV, dtype=torch.int32)
+    for b in range(B):
+        if int(bm[b]) != 0:
+            table[int(bm[b])] = lens[b]
+    q = torch.randn(B, HQ, D, generator=g).to(dtype).to(dev)
+    k1 = torch.randn(B, HKV, D, generator=g).to(dtype).to(dev)
+    v1 = torch.randn(B, HKV, D, generator=g).to(dtype).to(dev)
+    ptd, bmd = pt.to(dev), bm.to(dev)
+    # reference order
+    kc_a, vc_a, tab_a = kc.to(dev), vc.to(dev), table.to(dev)
+    sl = tab_a.index_select(0, bmd).contiguous()
+    decode_store_kv(key=k1, value=v1, batch_mapping=bmd, bh_lens=sl, page_table=ptd, k_cache=kc_a, v_cache=vc_a,
+                    PAGE_SIZE=PS)
+    o_a = head_sparse_decode_attention(q, kc_a, vc_a, sl, ptd, bmd, HKV, PS)
+    keep = bmd != 0
+    tab_a.index_copy_(0, bmd[keep].long(), sl[keep])
+    # fused
+    kc_b, vc_b, tab_b = kc.to(dev), vc.to(dev), table.to(dev)
+    o_b = fused_decode_step(q, k1, v1, kc_b, vc_b, tab_b, ptd, bmd, HKV, PS)
+    torch.cuda.synchronize()
+    assert torch.equal(tab_a, tab_b) and torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+    assert torch.equal(o_a[keep], o_b[keep])
+    assert (o_b[2] == 0).all()

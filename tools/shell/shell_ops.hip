@@ -62,13 +62,15 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(uint16_t* __restrict__
 // s_n -> dst contiguous [N, H, 128].  one wave per (token, head): lane l handles dims l and l+64.
 __global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ src, int64_t s_n,
                                                    uint16_t* __restrict__ dst, const int64_t* __restrict__ pos,
-                                                   const float* __restrict__ cs, const uint16_t* __restrict__ nw,
-                                                   int N, int H, float eps) {
+                                                   const float* __restrict__ cs, const uint16_t* __restrict__ nwq,
+                                                   const uint16_t* __restrict__ nwk, int N, int H, int HQ,
+                                                   float eps) {
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (long)N * H) return;
   const int n = (int)(wid / H), hh = (int)(wid % H), l = threadIdx.x & 63;
   const uint16_t* sp = src + (size_t)n * s_n + (size_t)hh * 128;
   float a = bf2f(sp[l]), b = bf2f(sp[l + 64]);
+  const uint16_t* nw = hh < HQ ? nwq : nwk;  // heads [0,HQ) are queries, [HQ,H) keys (q/k-norm weights differ)
   if (nw) {
     const float inv = rsqrtf(wave_sum(a * a + b * b) / 128.f + eps);
     a = bf2f(f2bf(a * inv * bf2f(nw[l])));
@@ -108,13 +110,13 @@ extern "C" void shell_add_rmsnorm(void* h, const void* delta, const void* w, voi
     hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (uint16_t*)h,
                        (const uint16_t*)delta, (const uint16_t*)w, (uint16_t*)y, C, eps);
 }
-extern "C" void shell_rope(const void* src, int64_t s_n, void* dst, const void* pos, const void* cs, const void* nw,
-                           int N, int H, float eps, void* stream) {
+extern "C" void shell_rope(const void* src, int64_t s_n, void* dst, const void* pos, const void* cs, const void* nwq,
+                           const void* nwk, int N, int H, int HQ, float eps, void* stream) {
   const long waves = (long)N * H;
   if (waves > 0)
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)src, s_n, (uint16_t*)dst, (const int64_t*)pos, (const float*)cs,
-                       (const uint16_t*)nw, N, H, eps);
+                       (const uint16_t*)nwq, (const uint16_t*)nwk, N, H, HQ, eps);
 }
 extern "C" void shell_silu_mul(const void* gu, void* out, long N, int I, void* stream) {
   const long total = N * I;
