@@ -24,12 +24,13 @@ _workspaces: dict = {}
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Persistent per-(device, stream) scratch so decode stays graph-capture safe (no allocation
-    inside the captured region after the first, un-captured, warm-up call)."""
+    """Persistent per-(device, stream) scratch so decode stays graph-capture safe (no allocation inside the
+    captured region after the first, un-captured, warm-up call).  ZERO-initialised: its first 64 KiB hold the
+    split-merge ticket counters, which the kernel leaves at zero after every launch."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        buf = torch.zeros(max(nbytes, 4 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
 

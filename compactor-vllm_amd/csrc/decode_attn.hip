@@ -19,7 +19,6 @@
 namespace cvllm {
 
 constexpr int DEC_NW = 4;        // waves per workgroup
-static int g_lens_by_row = 0;    // set only inside cvllm_decode_append_attn (host side; launches are single-threaded)
 constexpr int DEC_PGCACHE = 512; // page ids cached in LDS per split
 
 template <int LPR>
@@ -249,15 +248,24 @@ __global__ __launch_bounds__(DEC_NW * 64, MINW) void decode_stage1_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stage 1, LDS-ring form (the default).  A single CU sustains only ~24 GB/s of HBM loads, so reaching the
-// chip rate needs every CU busy with >= ~64 KiB in flight for the whole launch.  Registers cannot hold
-// that, LDS can: each wave owns a private ring of R unit slots in LDS and fills it with
-// global_load_lds_dwordx4 (LDS-DMA: lane l's 16 B land at slot + 16*l, the same coalesced row image),
-// keeps R-1 units in flight behind a COUNTED s_waitcnt vmcnt, and pulls the landed unit into registers
-// with ds_read_b128.  Rings are wave-private: no barrier in the loop.  The ds_reads and waits are inline
-// asm because hipcc otherwise drains vmcnt(0) before any LDS read while an LDS-DMA is pending.
-// Page ids of the split live in VGPRs (lane i holds page i) and are fetched with v_readlane: the loop has
-// no other memory instruction.
+// The decode kernel (default): LDS-ring streaming + in-launch split merge + optional fused cache append.
+//
+// * A single CU sustains only ~24 GB/s of HBM loads, so the chip rate needs every CU busy with >= ~64 KiB in
+//   flight for the whole launch.  Registers cannot hold that, LDS can: each wave owns a private ring of R unit
+//   slots in LDS and fills it with global_load_lds_dwordx4 (LDS-DMA, non-temporal: lane l's 16 B land at
+//   slot + 16*l, the same coalesced row image), keeps R-1 units in flight behind a COUNTED s_waitcnt vmcnt,
+//   and pulls the landed unit into registers with ds_read_b128.  Rings are wave-private: no barrier in the
+//   loop.  The ds_reads and waits are inline asm because hipcc otherwise drains vmcnt(0) before any LDS read
+//   while an LDS-DMA is pending.  Page ids of the split live in VGPRs (lane i holds page i) and are fetched
+//   with v_readlane: the loop has no other memory instruction.
+// * Splits of one (b, kv-head) are merged by a second, tiny kernel.  (An in-launch last-arriver merge was built
+//   and measured: the agent-scope release + acquire fences and the single merger's dependent L2 reads cost
+//   ~17 us against 4.6 us + one launch boundary for the separate kernel, so the seam is cut — CDNA guide 5.6.)
+// * Fused append (key_new != NULL): the new token's K/V row of (b,h) belongs at position L_old.  Every
+//   workgroup uses L = L_old + 1; the workgroup whose split owns row L_old substitutes the row from registers
+//   and writes it to the cache; the merge kernel (stream-ordered after every stage-1 workgroup has read L_old)
+//   publishes L_old + 1.  This replaces decode_store_kv + index_select/index_copy_ of the reference's decode
+//   branch (cv/layers/attention.py:127-160) with zero extra launches.
 template <int N>
 struct VmWait;
 #define CVLLM_VMWAIT(N)                                                             \
@@ -265,24 +273,25 @@ struct VmWait;
   struct VmWait<N> {                                                                \
     static __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); } \
   };
-CVLLM_VMWAIT(0) CVLLM_VMWAIT(4) CVLLM_VMWAIT(8) CVLLM_VMWAIT(12) CVLLM_VMWAIT(16) CVLLM_VMWAIT(24)
-CVLLM_VMWAIT(32) CVLLM_VMWAIT(36) CVLLM_VMWAIT(48) CVLLM_VMWAIT(56) CVLLM_VMWAIT(20) CVLLM_VMWAIT(28)
-CVLLM_VMWAIT(40)
+CVLLM_VMWAIT(0) CVLLM_VMWAIT(8) CVLLM_VMWAIT(12) CVLLM_VMWAIT(16) CVLLM_VMWAIT(24) CVLLM_VMWAIT(32)
 
-constexpr int DEC_PGREGS = 4;  // page ids cached in registers: 4 x 64 pages per split
+constexpr int DEC_PGREGS = 4;       // page ids cached in registers: 4 x 64 pages per split
+constexpr int DEC_MAX_SPLITS = 256;
 
-template <typename T, int D, int G, bool DIRECT, int NW, int NL, int R, bool NT, bool DBG_NOCOMPUTE = false>
-__global__ __launch_bounds__(NW * 64) void decode_stage1_ring_kernel(
-    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+template <typename T, int D, int G, int NW, int NL, int R>
+__global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
+    const uint16_t* __restrict__ q, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
-    const int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
-    int HKV, int PS, int NLP, int S, float scale, int lens_by_row) {
+    int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
+    const uint16_t* __restrict__ key_new, const uint16_t* __restrict__ val_new, int64_t sk_b, int64_t sk_h,
+    int64_t sv_b, int64_t sv_h, int HKV, int PS, int NLP, int S, float scale, int lens_by_row, int reserved) {
   constexpr int LPR = D / 8;
   constexpr int RPL = 64 / LPR;
   constexpr int UR = RPL * NL;
   constexpr int ROUND = UR * NW;
   constexpr int UNIT_BYTES = 2 * NL * 1024;  // K loads then V loads
   constexpr int P = R - 1;                   // units in flight ahead of the one being reduced
+  constexpr int NT_AUX = 2;                  // non-temporal: K/V are read once per step
   static_assert(2 * NL * P <= 60, "vmcnt is a 6-bit counter");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,106 +306,111 @@ __global__ __launch_bounds__(NW * 64) void decode_stage1_ring_kernel(
   const int h = bh % HKV;
   const int b = bh / HKV;
   const int HQ = HKV * G;
-  // lens_by_row: seq_lens is the layer's full [Bmax+1, HKV] table indexed by the TRUE batch row (fused decode)
-  const int L = seq_lens[lens_by_row ? bmap[b] * HKV + h : bh];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int c = lane / LPR;
   const int dl = lane % LPR;
 
+  const int bt = bmap[b];
+  const int lidx = lens_by_row ? bt * HKV + h : bh;
+  const bool append = key_new != nullptr && bt != reserved;
+  const int L_old = seq_lens[lidx];
+  const int L = (key_new != nullptr && bt == reserved) ? 0 : L_old + (append ? 1 : 0);
+
   int per = (L + S - 1) / S;
   per = (per + ROUND - 1) / ROUND * ROUND;
   const int start = s * per;
   const int end = min(start + per, L);
+  const bool empty = start >= end;
+  const bool owns_new = append && !empty && L_old >= start && L_old < end;
 
-  if (start >= end) {
-    if (DIRECT) {
-      for (int i = tid; i < G * D; i += NW * 64) out[((size_t)b * HQ + h * G) * D + i] = 0;
-    } else if (tid < G) {
-      part_lse[(size_t)(b * S + s) * HQ + h * G + tid] = -INFINITY;
+  float* po = part_o + ((size_t)(b * S + s) * HQ + h * G) * D;
+  float* pl = part_lse + (size_t)(b * S + s) * HQ + h * G;
+
+  if (!empty) {
+    const int* pt = page_table + ((size_t)bt * HKV + h) * NLP;
+    const int lp0 = start / PS;
+    const int nlp = (end - 1) / PS - lp0 + 1;  // <= 64 * DEC_PGREGS (checked on the host)
+    int pgreg[DEC_PGREGS];
+#pragma unroll
+    for (int j = 0; j < DEC_PGREGS; ++j) {
+      const int i = lane + 64 * j;
+      pgreg[j] = i < nlp ? pt[lp0 + i] : 0;
     }
-    return;
-  }
-
-  const int bt = bmap[b];
-  const int* pt = page_table + ((size_t)bt * HKV + h) * NLP;
-  const int lp0 = start / PS;
-  const int nlp = (end - 1) / PS - lp0 + 1;  // <= 64 * DEC_PGREGS (checked on the host)
-  int pgreg[DEC_PGREGS];
+    uint4 qf[G];
 #pragma unroll
-  for (int j = 0; j < DEC_PGREGS; ++j) {
-    const int i = lane + 64 * j;
-    pgreg[j] = i < nlp ? pt[lp0 + i] : 0;
-  }
-
-  uint4 qf[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-    qf[g] = *reinterpret_cast<const uint4*>(q + ((size_t)b * HQ + h * G + g) * D + dl * 8);
-
-  float m[G], l[G], acc[G][8];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    m[g] = -INFINITY;
-    l[g] = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) acc[g][d] = 0.f;
-  }
-
-  // Retire every ordinary load before the first LDS-DMA and hide the registers' origin from hipcc: it would
-  // otherwise wait vmcnt(0) at each later use of q / page ids, draining the ring every iteration.
-#pragma unroll
-  for (int j = 0; j < DEC_PGREGS; ++j) asm volatile("" : "+v"(pgreg[j]));
-#pragma unroll
-  for (int g = 0; g < G; ++g) asm volatile("" : "+v"(qf[g].x), "+v"(qf[g].y), "+v"(qf[g].z), "+v"(qf[g].w));
-
-  const int nunits = (end - start + UR - 1) / UR;
-  const int njw = nunits > wave ? (nunits - wave + NW - 1) / NW : 0;  // units owned by this wave
-  char* ring = smem + wave * (R * UNIT_BYTES);
-  const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
-  const uint32_t lane_off = lane * 16;
-
-  auto page_of = [&](int lpi) {
-    int pg = __builtin_amdgcn_readlane(pgreg[0], lpi & 63);
-#pragma unroll
-    for (int j = 1; j < DEC_PGREGS; ++j)
-      if ((lpi >> 6) == j) pg = __builtin_amdgcn_readlane(pgreg[j], lpi & 63);
-    return pg;
-  };
-
-  auto issue = [&](int j) {  // wave-local unit j -> ring slot j % R
-    const int row0 = start + (wave + j * NW) * UR;
-    const int pg = page_of(row0 / PS - lp0);
-    const size_t base = ((size_t)pg * PS + (row0 % PS) + c) * D + dl * 8;
-    char* slot = ring + (j % R) * UNIT_BYTES;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const uint16_t* kp = kc + base + (size_t)i * RPL * D;
-      const uint16_t* vp = vc + base + (size_t)i * RPL * D;
-      constexpr int AUX = NT ? 2 : 0;  // nt: once-read stream, do not keep in L2
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
-                                       (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, AUX);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
-                                       (__attribute__((address_space(3))) void*)(slot + (NL + i) * 1024), 16, 0, AUX);
+    for (int g = 0; g < G; ++g)
+      qf[g] = *reinterpret_cast<const uint4*>(q + ((size_t)b * HQ + h * G + g) * D + dl * 8);
+    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
+    if (owns_new) {
+      knew = *reinterpret_cast<const uint4*>(key_new + b * sk_b + h * sk_h + dl * 8);
+      vnew = *reinterpret_cast<const uint4*>(val_new + b * sv_b + h * sv_h + dl * 8);
     }
-  };
+    // Retire every ordinary load before the first LDS-DMA and hide the registers' origin from hipcc: it would
+    // otherwise wait vmcnt(0) at each later use of q / page ids, draining the ring every iteration.
+#pragma unroll
+    for (int j = 0; j < DEC_PGREGS; ++j) asm volatile("" : "+v"(pgreg[j]));
+#pragma unroll
+    for (int g = 0; g < G; ++g) asm volatile("" : "+v"(qf[g].x), "+v"(qf[g].y), "+v"(qf[g].z), "+v"(qf[g].w));
+    asm volatile("" : "+v"(knew.x), "+v"(knew.y), "+v"(knew.z), "+v"(knew.w));
+    asm volatile("" : "+v"(vnew.x), "+v"(vnew.y), "+v"(vnew.z), "+v"(vnew.w));
+
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      m[g] = -INFINITY;
+      l[g] = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[g][d] = 0.f;
+    }
+
+    const int nunits = (end - start + UR - 1) / UR;
+    const int njw = nunits > wave ? (nunits - wave + NW - 1) / NW : 0;  // units owned by this wave
+    char* ring = smem + wave * (R * UNIT_BYTES);
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    const uint32_t lane_off = lane * 16;
+
+    auto page_of = [&](int lpi) {
+      int pg = __builtin_amdgcn_readlane(pgreg[0], lpi & 63);
+#pragma unroll
+      for (int j = 1; j < DEC_PGREGS; ++j)
+        if ((lpi >> 6) == j) pg = __builtin_amdgcn_readlane(pgreg[j], lpi & 63);
+      return pg;
+    };
+
+    auto issue = [&](int j) {  // wave-local unit j -> ring slot j % R
+      const int row0 = start + (wave + j * NW) * UR;
+      const int pg = page_of(row0 / PS - lp0);
+      const size_t base = ((size_t)pg * PS + (row0 % PS) + c) * D + dl * 8;
+      char* slot = ring + (j % R) * UNIT_BYTES;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const uint16_t* kp = kc + base + (size_t)i * RPL * D;
+        const uint16_t* vp = vc + base + (size_t)i * RPL * D;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
+                                         (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, NT_AUX);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
+                                         (__attribute__((address_space(3))) void*)(slot + (NL + i) * 1024), 16, 0,
+                                         NT_AUX);
+      }
+    };
 
 #pragma unroll
-  for (int j = 0; j < P; ++j)
-    if (j < njw) issue(j);
+    for (int j = 0; j < P; ++j)
+      if (j < njw) issue(j);
 
-  for (int j = 0; j < njw; ++j) {
-    if (j + P < njw) {
-      issue(j + P);
-      VmWait<2 * NL * P>::wait();
-    } else {
-      VmWait<0>::wait();  // tail: drain
-    }
-    uint4 kk[NL], vv[NL];
-    {
-      const uint32_t a = ring_lds + (j % R) * UNIT_BYTES + lane_off;
-      if constexpr (NL == 4) {
+    for (int j = 0; j < njw; ++j) {
+      if (j + P < njw) {
+        issue(j + P);
+        VmWait<2 * NL * P>::wait();
+      } else {
+        VmWait<0>::wait();  // tail: drain
+      }
+      uint4 kk[NL], vv[NL];
+      {
+        const uint32_t a = ring_lds + (j % R) * UNIT_BYTES + lane_off;
+        static_assert(NL == 4, "unit = 4 K loads + 4 V loads");
         asm volatile(
             "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
             "ds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\t"
@@ -405,150 +419,173 @@ __global__ __launch_bounds__(NW * 64) void decode_stage1_ring_kernel(
               "=&v"(vv[3])
             : "v"(a)
             : "memory");
-      } else {
-        static_assert(NL == 2, "NL must be 2 or 4");
-        asm volatile(
-            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
-            "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-            : "=&v"(kk[0]), "=&v"(kk[1]), "=&v"(vv[0]), "=&v"(vv[1])
-            : "v"(a)
-            : "memory");
       }
-    }
-    const int rbase = start + (wave + j * NW) * UR + c;
-    if (DBG_NOCOMPUTE) {  // timing experiment: stream only (results are garbage)
+      const int rbase = start + (wave + j * NW) * UR + c;
+      if (owns_new) {  // the appended row comes from registers (its cache slot still holds stale bytes)
 #pragma unroll
-      for (int i = 0; i < NL; ++i) acc[0][i & 7] += __uint_as_float((kk[i].x ^ vv[i].w) & 0x3fffffffu);
-      continue;
-    }
-    float sc[NL][G];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float a = dot2<T>(kk[i].x, qf[g].x, 0.f);
-        a = dot2<T>(kk[i].y, qf[g].y, a);
-        a = dot2<T>(kk[i].z, qf[g].z, a);
-        a = dot2<T>(kk[i].w, qf[g].w, a);
-        sc[i][g] = a;
+        for (int i = 0; i < NL; ++i) {
+          const bool is_new = (rbase + i * RPL) == L_old;
+          kk[i].x = is_new ? knew.x : kk[i].x; kk[i].y = is_new ? knew.y : kk[i].y;
+          kk[i].z = is_new ? knew.z : kk[i].z; kk[i].w = is_new ? knew.w : kk[i].w;
+          vv[i].x = is_new ? vnew.x : vv[i].x; vv[i].y = is_new ? vnew.y : vv[i].y;
+          vv[i].z = is_new ? vnew.z : vv[i].z; vv[i].w = is_new ? vnew.w : vv[i].w;
+        }
       }
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const bool valid = (rbase + i * RPL) < end;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float r = group_allreduce_sum<LPR>(sc[i][g]);
-        sc[i][g] = valid ? r * scale : -INFINITY;
-      }
-    }
-    float vf[NL][8];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const bool valid = (rbase + i * RPL) < end;
-      float2 t0 = unpack2<T>(vv[i].x), t1 = unpack2<T>(vv[i].y), t2 = unpack2<T>(vv[i].z), t3 = unpack2<T>(vv[i].w);
-      vf[i][0] = valid ? t0.x : 0.f; vf[i][1] = valid ? t0.y : 0.f;
-      vf[i][2] = valid ? t1.x : 0.f; vf[i][3] = valid ? t1.y : 0.f;
-      vf[i][4] = valid ? t2.x : 0.f; vf[i][5] = valid ? t2.y : 0.f;
-      vf[i][6] = valid ? t3.x : 0.f; vf[i][7] = valid ? t3.y : 0.f;
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float mx = m[g];
-#pragma unroll
-      for (int i = 0; i < NL; ++i) mx = fmaxf(mx, sc[i][g]);
-      const float mxs = (mx == -INFINITY) ? 0.f : mx;
-      const float alpha = __expf(m[g] - mxs);
-      float p[NL];
-      float ps = 0.f;
+      float sc[NL][G];
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        p[i] = __expf(sc[i][g] - mxs);
-        ps += p[i];
-      }
-      l[g] = l[g] * alpha + ps;
-      m[g] = mx;
 #pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        float a = acc[g][d] * alpha;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) a = fmaf(p[i], vf[i][d], a);
-        acc[g][d] = a;
+        for (int g = 0; g < G; ++g) {
+          float a = dot2<T>(kk[i].x, qf[g].x, 0.f);
+          a = dot2<T>(kk[i].y, qf[g].y, a);
+          a = dot2<T>(kk[i].z, qf[g].z, a);
+          a = dot2<T>(kk[i].w, qf[g].w, a);
+          sc[i][g] = a;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const bool valid = (rbase + i * RPL) < end;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float r = group_allreduce_sum<LPR>(sc[i][g]);
+          sc[i][g] = valid ? r * scale : -INFINITY;
+        }
+      }
+      float vf[NL][8];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const bool valid = (rbase + i * RPL) < end;
+        float2 t0 = unpack2<T>(vv[i].x), t1 = unpack2<T>(vv[i].y), t2 = unpack2<T>(vv[i].z), t3 = unpack2<T>(vv[i].w);
+        vf[i][0] = valid ? t0.x : 0.f; vf[i][1] = valid ? t0.y : 0.f;
+        vf[i][2] = valid ? t1.x : 0.f; vf[i][3] = valid ? t1.y : 0.f;
+        vf[i][4] = valid ? t2.x : 0.f; vf[i][5] = valid ? t2.y : 0.f;
+        vf[i][6] = valid ? t3.x : 0.f; vf[i][7] = valid ? t3.y : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float mx = m[g];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) mx = fmaxf(mx, sc[i][g]);
+        const float mxs = (mx == -INFINITY) ? 0.f : mx;
+        const float alpha = __expf(m[g] - mxs);
+        float p[NL];
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          p[i] = __expf(sc[i][g] - mxs);
+          ps += p[i];
+        }
+        l[g] = l[g] * alpha + ps;
+        m[g] = mx;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          float a = acc[g][d] * alpha;
+#pragma unroll
+          for (int i = 0; i < NL; ++i) a = fmaf(p[i], vf[i][d], a);
+          acc[g][d] = a;
+        }
+      }
+    }
+
+    if (owns_new) {  // write the appended row into the paged cache (one 16-lane group owns it)
+      const int u = (L_old - start) / UR;  // unit of the new row
+      if ((u % NW) == wave && c == ((L_old - start) % UR) % RPL) {
+        const int pg = page_of(L_old / PS - lp0);
+        const size_t dst = ((size_t)pg * PS + L_old % PS) * D + dl * 8;
+        *reinterpret_cast<uint4*>(kc + dst) = knew;
+        *reinterpret_cast<uint4*>(vc + dst) = vnew;
+      }
+    }
+
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float mo = __shfl_xor(m[g], off, 64);
+        const float lo = __shfl_xor(l[g], off, 64);
+        const float mx = fmaxf(m[g], mo);
+        const float mxs = (mx == -INFINITY) ? 0.f : mx;
+        const float a0 = __expf(m[g] - mxs), a1 = __expf(mo - mxs);
+        l[g] = l[g] * a0 + lo * a1;
+        m[g] = mx;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const float ao = __shfl_xor(acc[g][d], off, 64);
+          acc[g][d] = acc[g][d] * a0 + ao * a1;
+        }
+      }
+    }
+    if (c == 0) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (dl == 0) {
+          s_m[wave * G + g] = m[g];
+          s_l[wave * G + g] = l[g];
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s_acc[(wave * G + g) * D + dl * 8 + d] = acc[g][d];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * D; idx += NW * 64) {
+      const int g = idx / D, d = idx % D;
+      float M = s_m[g];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w * G + g]);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float a = __expf(s_m[w * G + g] - M);  // M finite: wave 0 always owns a valid row
+        num += a * s_acc[(w * G + g) * D + d];
+        den += a * s_l[w * G + g];
+      }
+      const float o = num / den;
+      if (S == 1) {
+        out[((size_t)b * HQ + h * G + g) * D + d] = to16<T>(o);
+      } else {
+        po[g * D + d] = o;
+        if (d == 0) pl[g] = M + __logf(den);
+      }
+    }
+  } else {  // empty split (covers L == 0 and RESERVED rows)
+    if (S == 1) {
+      for (int i = tid; i < G * D; i += NW * 64) out[((size_t)b * HQ + h * G) * D + i] = 0;
+    } else if (tid < G) {
+      pl[tid] = -INFINITY;
     }
   }
 
-#pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float mo = __shfl_xor(m[g], off, 64);
-      const float lo = __shfl_xor(l[g], off, 64);
-      const float mx = fmaxf(m[g], mo);
-      const float mxs = (mx == -INFINITY) ? 0.f : mx;
-      const float a0 = __expf(m[g] - mxs), a1 = __expf(mo - mxs);
-      l[g] = l[g] * a0 + lo * a1;
-      m[g] = mx;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        const float ao = __shfl_xor(acc[g][d], off, 64);
-        acc[g][d] = acc[g][d] * a0 + ao * a1;
-      }
-    }
-  }
-  if (c == 0) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (dl == 0) {
-        s_m[wave * G + g] = m[g];
-        s_l[wave * G + g] = l[g];
-      }
-#pragma unroll
-      for (int d = 0; d < 8; ++d) s_acc[(wave * G + g) * D + dl * 8 + d] = acc[g][d];
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < G * D; idx += NW * 64) {
-    const int g = idx / D, d = idx % D;
-    float M = s_m[g];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w * G + g]);
-    float num = 0.f, den = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float a = __expf(s_m[w * G + g] - M);  // M finite: wave 0 always owns a valid row
-      num += a * s_acc[(w * G + g) * D + d];
-      den += a * s_l[w * G + g];
-    }
-    const float o = num / den;
-    if (DIRECT) {
-      out[((size_t)b * HQ + h * G + g) * D + d] = to16<T>(o);
-    } else {
-      part_o[((size_t)(b * S + s) * HQ + h * G + g) * D + d] = o;
-      if (d == 0) part_lse[(size_t)(b * S + s) * HQ + h * G + g] = M + __logf(den);
-    }
-  }
+  // S == 1: this is the only workgroup of (b,h) and it has consumed L_old -> publish the new length here.
+  // S > 1: the merge kernel (stream-ordered after every stage-1 workgroup) publishes it.
+  if (S == 1 && append && tid == 0) seq_lens[lidx] = L_old + 1;
 }
 
 template <int D, int G, int NW, int NL, int R>
 constexpr size_t ring_smem_bytes() {
-  return (size_t)NW * R * 2 * NL * 1024 + ((size_t)NW * G * D + 2 * NW * G) * sizeof(float);
+  return (size_t)NW * R * 2 * NL * 1024 + ((size_t)NW * G * D + 2 * NW * G) * sizeof(float) + 16;
 }
 
 // stage 2: LSE-weighted merge of the S partials of one (b, query head)   (reference :391-435)
 // 4 waves per (b, hq): every wave first reads all S lse values (<= 256), then waves take the splits
 // round-robin with independent, unrolled loads; the four partial sums meet in LDS.
-constexpr int DEC_MAX_SPLITS = 256;
 template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_stage2_kernel(const float* __restrict__ part_o,
                                                            const float* __restrict__ part_lse,
-                                                           uint16_t* __restrict__ out, int HQ, int S) {
+                                                           uint16_t* __restrict__ out, int HQ, int S,
+                                                           int* __restrict__ seq_lens, const int* __restrict__ bmap,
+                                                           int G, int append, int lens_by_row, int reserved) {
   constexpr int VPT = D / 64;  // values per lane
   __shared__ float s_acc[4][D];
   const int bhq = blockIdx.x;
   const int b = bhq / HQ, hq = bhq % HQ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (append && tid == 0 && (hq % G) == 0) {  // fused append: publish L_old + 1 (every stage-1 reader is done)
+    const int bt = bmap[b];
+    const int HKV = HQ / G, h = hq / G;
+    if (bt != reserved) seq_lens[lens_by_row ? bt * HKV + h : b * HKV + h] += 1;
+  }
   float lse[DEC_MAX_SPLITS / 64];
   float M = -INFINITY;
 #pragma unroll
@@ -599,131 +636,93 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(const float* __restr
   }
 }
 
-static int g_decode_variant = 0;  // tuning knob for tools/microbench.py (see launch_decode)
+static hipEvent_t g_evt_start = nullptr, g_evt_stop = nullptr;  // bench.py roofline leg
 
-template <typename T, int D, int G, int NL, int MINW>
-static int launch_decode_v(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
-                           const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
-                           float scale, int S, hipStream_t st) {
-  const int HQ = HKV * G;
-  float* part_o = ws;
-  float* part_lse = ws + (size_t)B * S * HQ * D;
-  dim3 grid(B * HKV * S), block(DEC_NW * 64);
-  if (S == 1) {
-    hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, true, NL, MINW>), grid, block, 0, st, (const uint16_t*)q,
-                       (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
-                       page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
-    return check_launch();
-  }
-  hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, false, NL, MINW>), grid, block, 0, st, (const uint16_t*)q,
-                     (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, part_o, part_lse, seq_lens,
-                     page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
-  hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
-                     (uint16_t*)out, HQ, S);
-  return check_launch();
-}
+struct DecodeArgs {
+  const void *q, *key_new, *val_new;
+  void *kc, *vc, *out;
+  int* seq_lens;
+  const int *page_table, *bmap;
+  float* ws;
+  int64_t sk_b, sk_h, sv_b, sv_h;
+  int B, HKV, PS, NLP, S, lens_by_row, reserved;
+  float scale;
+  hipStream_t st;
+};
 
-static hipEvent_t g_evt_start = nullptr, g_evt_stop = nullptr;  // bench.py roofline leg (stage-1 only)
-static int g_decode_nt = 1;  // K/V are read once per step: non-temporal LDS-DMA measured 5-8% faster
-static int g_decode_nocompute = 0;
 
-template <typename T, int D, int G, int NW, int NL, int R, bool NT>
-static int launch_decode_ring_nt(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
-                              const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
-                              float scale, int S, hipStream_t st) {
-  const int HQ = HKV * G;
-  float* part_o = ws;
-  float* part_lse = ws + (size_t)B * S * HQ * D;
+
+template <typename T, int D, int G>
+static int launch_fused(const DecodeArgs& a) {
+  constexpr int NW = 4, NL = 4, R = 4;
+  const int HQ = a.HKV * G;
+  float* part_o = a.ws;
+  float* part_lse = part_o + (size_t)a.B * a.S * HQ * D;
   constexpr size_t smem = ring_smem_bytes<D, G, NW, NL, R>();
   static_assert(smem <= 160 * 1024, "LDS budget");
-  dim3 grid(B * HKV * S), block(NW * 64);
-  static bool attr_done[2] = {false, false};
-  if (S == 1) {
-    auto kern = decode_stage1_ring_kernel<T, D, G, true, NW, NL, R, NT>;
-    if (!attr_done[0]) {
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_done[0] = true;
-    }
-    hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
-                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
-    return check_launch();
+  auto kern = decode_fused_kernel<T, D, G, NW, NL, R>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
   }
-  if (g_decode_nocompute) {
-    auto kern = decode_stage1_ring_kernel<T, D, G, false, NW, NL, R, NT, true>;
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
-                       (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
-    return check_launch();
-  }
-  auto kern = decode_stage1_ring_kernel<T, D, G, false, NW, NL, R, NT>;
-  if (!attr_done[1]) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done[1] = true;
-  }
-  if (g_evt_start) (void)hipEventRecord(g_evt_start, st);
-  hipLaunchKernelGGL(kern, grid, block, smem, st, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,
-                     (uint16_t*)out, part_o, part_lse, seq_lens, page_table, bmap, HKV, PS, NLP, S, scale, g_lens_by_row);
-  if (g_evt_stop) (void)hipEventRecord(g_evt_stop, st);
-  hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(B * HQ), dim3(256), 0, st, part_o, part_lse,
-                     (uint16_t*)out, HQ, S);
+  if (g_evt_start) (void)hipEventRecord(g_evt_start, a.st);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.HKV * a.S), dim3(NW * 64), smem, a.st, (const uint16_t*)a.q, (uint16_t*)a.kc,
+                     (uint16_t*)a.vc, (uint16_t*)a.out, part_o, part_lse, a.seq_lens, a.page_table, a.bmap,
+                     (const uint16_t*)a.key_new, (const uint16_t*)a.val_new, a.sk_b, a.sk_h, a.sv_b, a.sv_h, a.HKV,
+                     a.PS, a.NLP, a.S, a.scale, a.lens_by_row, a.reserved);
+  if (g_evt_stop) (void)hipEventRecord(g_evt_stop, a.st);
+  if (a.S > 1)
+    hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(a.B * HQ), dim3(256), 0, a.st, part_o, part_lse,
+                       (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, a.key_new != nullptr ? 1 : 0, a.lens_by_row,
+                       a.reserved);
   return check_launch();
 }
 
-template <typename T, int D, int G, int NW, int NL, int R>
-static int launch_decode_ring(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
-                              const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
-                              float scale, int S, hipStream_t st) {
-  if (g_decode_nt)
-    return launch_decode_ring_nt<T, D, G, NW, NL, R, true>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS,
-                                                           NLP, scale, S, st);
-  return launch_decode_ring_nt<T, D, G, NW, NL, R, false>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS,
-                                                          NLP, scale, S, st);
+// D = 256 fallback: register double-buffered stage 1 + separate merge kernel (no fused append)
+template <typename T, int D, int G>
+static int launch_fallback(const DecodeArgs& a) {
+  const int HQ = a.HKV * G;
+  float* part_o = a.ws;
+  float* part_lse = part_o + (size_t)a.B * a.S * HQ * D;
+  dim3 grid(a.B * a.HKV * a.S), block(DEC_NW * 64);
+  if (a.S == 1) {
+    hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, true, 4, 2>), grid, block, 0, a.st, (const uint16_t*)a.q,
+                       (const uint16_t*)a.kc, (const uint16_t*)a.vc, (uint16_t*)a.out, part_o, part_lse, a.seq_lens,
+                       a.page_table, a.bmap, a.HKV, a.PS, a.NLP, a.S, a.scale, a.lens_by_row);
+    return check_launch();
+  }
+  hipLaunchKernelGGL((decode_stage1_kernel<T, D, G, false, 4, 2>), grid, block, 0, a.st, (const uint16_t*)a.q,
+                     (const uint16_t*)a.kc, (const uint16_t*)a.vc, (uint16_t*)a.out, part_o, part_lse, a.seq_lens,
+                     a.page_table, a.bmap, a.HKV, a.PS, a.NLP, a.S, a.scale, a.lens_by_row);
+  hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(a.B * HQ), dim3(256), 0, a.st, part_o, part_lse,
+                     (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, 0, a.lens_by_row, a.reserved);
+  return check_launch();
 }
 
 template <typename T, int D, int G>
-static int launch_decode(const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
-                         const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
-                         float scale, int S, hipStream_t st) {
-#define RING(NW_, NL_, R_) \
-  return launch_decode_ring<T, D, G, NW_, NL_, R_>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st)
-  if constexpr (D == 128 && G == 4) {  // the tuned shape: variants selectable for tools/microbench.py
-    switch (g_decode_variant) {
-      case 1: return launch_decode_v<T, D, G, 4, 2>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-      case 2: RING(4, 4, 3);
-      case 3: RING(8, 2, 4);
-      case 4: RING(8, 4, 2);
-      case 5: RING(8, 2, 3);
-      case 6: RING(4, 2, 4);
-      case 7: RING(4, 2, 8);
-      default: RING(4, 4, 4);
-    }
-  }
-  if constexpr (D <= 128) RING(4, 4, 4);
-  return launch_decode_v<T, D, G, 4, 2>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-#undef RING
+static int launch_decode(const DecodeArgs& a) {
+  if constexpr (D <= 128) return launch_fused<T, D, G>(a);
+  else return launch_fallback<T, D, G>(a);
 }
 
 template <typename T, int D>
-static int dispatch_g(int G, const void* q, const void* kc, const void* vc, void* out, const int* seq_lens,
-                      const int* page_table, const int* bmap, float* ws, int B, int HKV, int PS, int NLP,
-                      float scale, int S, hipStream_t st) {
+static int dispatch_g(int G, const DecodeArgs& a) {
   switch (G) {
-    case 1: return launch_decode<T, D, 1>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-    case 2: return launch_decode<T, D, 2>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-    case 4: return launch_decode<T, D, 4>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-    case 8: return launch_decode<T, D, 8>(q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
+    case 1: return launch_decode<T, D, 1>(a);
+    case 2: return launch_decode<T, D, 2>(a);
+    case 4: return launch_decode<T, D, 4>(a);
+    case 8: return launch_decode<T, D, 8>(a);
     default: return CVLLM_ERR_SHAPE;
   }
 }
 
 template <typename T>
-static int dispatch_d(int D, int G, const void* q, const void* kc, const void* vc, void* out,
-                      const int* seq_lens, const int* page_table, const int* bmap, float* ws, int B, int HKV,
-                      int PS, int NLP, float scale, int S, hipStream_t st) {
+static int dispatch_d(int D, int G, const DecodeArgs& a) {
   switch (D) {
-    case 64: return dispatch_g<T, 64>(G, q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-    case 128: return dispatch_g<T, 128>(G, q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
-    case 256: return dispatch_g<T, 256>(G, q, kc, vc, out, seq_lens, page_table, bmap, ws, B, HKV, PS, NLP, scale, S, st);
+    case 64: return dispatch_g<T, 64>(G, a);
+    case 128: return dispatch_g<T, 128>(G, a);
+    case 256: return dispatch_g<T, 256>(G, a);
     default: return CVLLM_ERR_SHAPE;
   }
 }
@@ -734,7 +733,23 @@ using namespace cvllm;
 
 extern "C" size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits) {
   if (B <= 0 || HQ <= 0 || D <= 0 || n_splits <= 0) return 0;
-  return ((size_t)B * n_splits * HQ * D + (size_t)B * n_splits * HQ) * sizeof(float);
+  return ((size_t)B * n_splits * HQ * D + (size_t)B * n_splits * HQ) * sizeof(float);  // fp32 partials | fp32 lse
+}
+
+static int decode_common(DecodeArgs a, int HQ, int D, int dtype, size_t workspace_bytes) {
+  if (!a.q || !a.kc || !a.vc || !a.out || !a.seq_lens || !a.page_table || !a.bmap) return CVLLM_ERR_ARG;
+  if (a.B <= 0 || HQ <= 0 || a.HKV <= 0 || a.S <= 0 || a.NLP <= 0) return CVLLM_ERR_ARG;
+  if (HQ % a.HKV != 0 || a.S > DEC_MAX_SPLITS) return CVLLM_ERR_SHAPE;
+  // a unit of (64/(D/8))*4 rows must not straddle a page; the reference requires PAGE_SIZE % 32 == 0 (:80)
+  if (a.PS <= 0 || a.PS % 32 != 0) return CVLLM_ERR_SHAPE;
+  // the ring kernel keeps a split's page ids in 4 VGPRs (256 pages): rows per split <= 256 * page_size
+  if ((a.NLP + a.S - 1) / a.S + 1 > 64 * DEC_PGREGS) return CVLLM_ERR_SHAPE;
+  if (a.S > 1 && (!a.ws || workspace_bytes < cvllm_decode_workspace_bytes(a.B, HQ, D, a.S))) return CVLLM_ERR_WORKSPACE;
+  if (a.key_new && D > 128) return CVLLM_ERR_SHAPE;  // fused append exists in the ring kernel only
+  const int G = HQ / a.HKV;
+  if (dtype == CVLLM_F16) return dispatch_d<F16>(D, G, a);
+  if (dtype == CVLLM_BF16) return dispatch_d<BF16>(D, G, a);
+  return CVLLM_ERR_SHAPE;
 }
 
 extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
@@ -742,25 +757,13 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
                                  const int32_t* batch_mapping, void* workspace, size_t workspace_bytes, int B,
                                  int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
                                  float sm_scale, int n_splits, int dtype, cvllm_stream_t stream) {
-  if (!q || !k_cache || !v_cache || !out || !seq_lens_bh || !page_table || !batch_mapping) return CVLLM_ERR_ARG;
-  if (B <= 0 || HQ <= 0 || HKV <= 0 || n_splits <= 0 || n_logical_pages_max <= 0) return CVLLM_ERR_ARG;
-  if (HQ % HKV != 0 || n_splits > DEC_MAX_SPLITS) return CVLLM_ERR_SHAPE;
-  // the ring kernel keeps a split's page ids in 4 VGPRs (256 pages): rows per split <= 256 * page_size
-  if ((n_logical_pages_max + n_splits - 1) / n_splits + 1 > 64 * DEC_PGREGS) return CVLLM_ERR_SHAPE;
-  // a unit of (64/(D/8))*4 rows must not straddle a page; the reference requires PAGE_SIZE % 32 == 0 (:80)
-  if (page_size <= 0 || page_size % 32 != 0) return CVLLM_ERR_SHAPE;
-  if (n_splits > 1) {
-    if (!workspace || workspace_bytes < cvllm_decode_workspace_bytes(B, HQ, D, n_splits)) return CVLLM_ERR_WORKSPACE;
-  }
-  const int G = HQ / HKV;
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVLLM_F16)
-    return dispatch_d<F16>(D, G, q, k_cache, v_cache, out, seq_lens_bh, page_table, batch_mapping,
-                           (float*)workspace, B, HKV, page_size, n_logical_pages_max, sm_scale, n_splits, st);
-  if (dtype == CVLLM_BF16)
-    return dispatch_d<BF16>(D, G, q, k_cache, v_cache, out, seq_lens_bh, page_table, batch_mapping,
-                            (float*)workspace, B, HKV, page_size, n_logical_pages_max, sm_scale, n_splits, st);
-  return CVLLM_ERR_SHAPE;
+  DecodeArgs a{};
+  a.q = q; a.kc = (void*)k_cache; a.vc = (void*)v_cache; a.out = out;
+  a.seq_lens = (int*)seq_lens_bh;  // read-only without an appended row
+  a.page_table = page_table; a.bmap = batch_mapping; a.ws = (float*)workspace;
+  a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 0;
+  a.reserved = -1; a.scale = sm_scale; a.st = (hipStream_t)stream;
+  return decode_common(a, HQ, D, dtype, workspace_bytes);
 }
 
 // Fused decode step of the boundary orchestrator (cv/layers/attention.py:127-160 decode branch): append the new
@@ -772,25 +775,22 @@ extern "C" int cvllm_decode_append_attn(const void* q, const void* key, const vo
                                         const int32_t* batch_mapping, void* workspace, size_t workspace_bytes, int B,
                                         int HQ, int HKV, int D, int page_size, int n_logical_pages_max, float sm_scale,
                                         int n_splits, int reserved_batch, int dtype, cvllm_stream_t stream) {
-  if (!key || !value || !bh_seq_lens) return CVLLM_ERR_ARG;
-  int st = cvllm::store_decode_kv_impl(key, value, sk_b, sk_h, sv_b, sv_h, batch_mapping, bh_seq_lens, page_table,
-                                       k_cache, v_cache, B, HKV, D, page_size, n_logical_pages_max, reserved_batch,
-                                       dtype, /*lens_by_row=*/1, stream);
-  if (st != CVLLM_OK) return st;
-  g_lens_by_row = 1;
-  st = cvllm_decode_attn(q, k_cache, v_cache, out, bh_seq_lens, page_table, batch_mapping, workspace, workspace_bytes,
-                         B, HQ, HKV, D, page_size, n_logical_pages_max, sm_scale, n_splits, dtype, stream);
-  g_lens_by_row = 0;
-  return st;
+  if (!key || !value) return CVLLM_ERR_ARG;
+  if ((sk_b % 8) || (sk_h % 8) || (sv_b % 8) || (sv_h % 8)) return CVLLM_ERR_SHAPE;
+  DecodeArgs a{};
+  a.q = q; a.key_new = key; a.val_new = value; a.kc = k_cache; a.vc = v_cache; a.out = out;
+  a.seq_lens = bh_seq_lens; a.page_table = page_table; a.bmap = batch_mapping; a.ws = (float*)workspace;
+  a.sk_b = sk_b; a.sk_h = sk_h; a.sv_b = sv_b; a.sv_h = sv_h;
+  a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 1;
+  a.reserved = reserved_batch; a.scale = sm_scale; a.st = (hipStream_t)stream;
+  return decode_common(a, HQ, D, dtype, workspace_bytes);
 }
 
-// bench.py: HIP events recorded immediately before / after the stage-1 launch on the launch stream (NULL = off)
+// bench.py: HIP events recorded immediately before / after the decode kernel launch on the launch stream
 extern "C" void cvllm_debug_set_decode_events(void* start, void* stop) {
   g_evt_start = (hipEvent_t)start;
   g_evt_stop = (hipEvent_t)stop;
 }
-
-extern "C" void cvllm_debug_set_decode_variant(int v) { g_decode_variant = v & 0xff; g_decode_nt = ((v >> 8) & 1) ^ 1; g_decode_nocompute = (v >> 9) & 1; }
 
 // Host restatement of num_splits_heuristic (cv/attention/sparse_decode_kernel.py:169-192).
 extern "C" int cvllm_num_splits(int total_mblocks, int max_seq_len, int num_sms, int max_splits) {

@@ -55,8 +55,7 @@ def bench_decode(args):
     splits_list = [args.splits] if args.splits else [16, 32, 64]
     bytes_alg = 2 * D * 2 * B * HKV * L + 2 * B * HQ * D * 2
     from compactor_vllm_amd import _lib
-    for variant in ([args.variant] if args.variant >= 0 else [0, 1, 2, 3, 4, 5, 6, 7, 0x100, 0x103]):
-        _lib.lib().cvllm_debug_set_decode_variant(variant)
+    for variant in [0]:
         for S in splits_list:
             dk.plan_internal_splits = lambda n_bh, bound, ks, S=S: S
             # one HIP graph with `layers` launches over distinct caches: no host launch overhead in the timing
