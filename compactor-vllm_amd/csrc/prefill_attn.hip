@@ -41,7 +41,7 @@ constexpr int PF_KT = 64;      // keys per tile
 constexpr int PF_THREADS = 512;
 constexpr int PF_TILE_BYTES = PF_KT * 256;        // one K or V tile image (256-byte rows)
 constexpr int PF_OSTRIDE = 272;                   // padded row stride of the O staging image
-constexpr int PF_SMEM = (4 * PF_TILE_BYTES > 8 * 32 * PF_OSTRIDE) ? 4 * PF_TILE_BYTES : 8 * 32 * PF_OSTRIDE;
+constexpr int PF_SMEM = (4 * PF_TILE_BYTES > 8 * 32 * PF_OSTRIDE) ? 4 * PF_TILE_BYTES : 8 * 32 * PF_OSTRIDE;  // 2 x (K + V)
 
 // K image: row-wise ds_read_b128 (T2 swizzle);  V image: transposed ds_read_b64_tr_b16 (guide T10 layout (b))
 __device__ __forceinline__ uint32_t k_off(int row, int ch) { return row * 256 + 16 * (ch ^ (row & 15)); }
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
     int64_t sk_n, int64_t sk_h, int64_t sv_n, int64_t sv_h, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, uint16_t* __restrict__ out, const int* __restrict__ seq_lens,
     const int* __restrict__ page_table, const int* __restrict__ bmap, const int* __restrict__ cu, int B, int HKV,
-    int PS, int NLP, float scale_log2e) {
+    int PS, int NLP, float scale_log2e, int dbg) {
   constexpr int BM = PF_ROWS / G;  // tokens per query tile
   constexpr int KS = D / 16;       // k-steps of the QK^T product
   constexpr int DB = D / 32;       // 32-wide blocks of the head dim
@@ -103,48 +103,44 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   const int nta = (la_vis + PF_KT - 1) / PF_KT;                   // appended tiles (last ones are on the diagonal)
   const int ntiles = ntc + nta;
 
-  // ---- staging: thread -> (rows srow, srow+32; chunk sch) of the K and V tiles ---------------------------------
+  // ---- staging: thread -> (rows srow, srow+32; chunk sch) of a K or V tile ------------------------------------
   const int sch = tid & 15;
   const int srow = tid >> 4;  // 0..31
   const bool stage_active = sch < CH;
-  uint4 kreg[2], vreg[2];
+  uint4 kr0, kr1, vr0, vr1;  // staged tile chunks (named scalars: arrays captured by the lambdas went to scratch)
 
+  // Source row offsets (in elements) of this thread's two rows of tile t (cached prefix first, then the appended
+  // block).  Rows past the end of the tile are CLAMPED to the last valid row instead of being skipped: their
+  // logits are masked to -inf (P = 0) and the clamped row is finite data, so 0 * V stays 0 - and the loads stay
+  // unconditional (a per-row "load or zero" select makes hipcc branch around every load and serialise them).
   auto gload = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int jj = srow + 32 * i;
-      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-      if (stage_active) {
-        if (t < ntc) {
-          const int pos = t * PF_KT + jj;
-          if (pos < Lc) {
-            const size_t rowp = (size_t)pt[pos / PS] * PS + pos % PS;  // int64 row offset (reference :371)
-            kv = *reinterpret_cast<const uint4*>(kc + rowp * D + sch * 8);
-            vv = *reinterpret_cast<const uint4*>(vc + rowp * D + sch * 8);
-          }
-        } else {
-          const int pos = (t - ntc) * PF_KT + jj;
-          if (pos < la_vis) {
-            const size_t n = (size_t)(s0 + pos);
-            kv = *reinterpret_cast<const uint4*>(k + n * sk_n + (size_t)g * sk_h + sch * 8);
-            vv = *reinterpret_cast<const uint4*>(v + n * sv_n + (size_t)g * sv_h + sch * 8);
-          }
-        }
+    if (stage_active) {
+      if (t < ntc) {
+        const int p0 = min(t * PF_KT + srow, Lc - 1), p1 = min(t * PF_KT + srow + 32, Lc - 1);
+        const size_t o0 = ((size_t)pt[p0 / PS] * PS + p0 % PS) * D + sch * 8;  // int64 row offset (reference :371)
+        const size_t o1 = ((size_t)pt[p1 / PS] * PS + p1 % PS) * D + sch * 8;
+        kr0 = *reinterpret_cast<const uint4*>(kc + o0);
+        kr1 = *reinterpret_cast<const uint4*>(kc + o1);
+        vr0 = *reinterpret_cast<const uint4*>(vc + o0);
+        vr1 = *reinterpret_cast<const uint4*>(vc + o1);
+      } else {
+        const int p0 = min((t - ntc) * PF_KT + srow, la_vis - 1), p1 = min((t - ntc) * PF_KT + srow + 32, la_vis - 1);
+        const size_t n0 = (size_t)(s0 + p0), n1 = (size_t)(s0 + p1);
+        kr0 = *reinterpret_cast<const uint4*>(k + n0 * sk_n + (size_t)g * sk_h + sch * 8);
+        kr1 = *reinterpret_cast<const uint4*>(k + n1 * sk_n + (size_t)g * sk_h + sch * 8);
+        vr0 = *reinterpret_cast<const uint4*>(v + n0 * sv_n + (size_t)g * sv_h + sch * 8);
+        vr1 = *reinterpret_cast<const uint4*>(v + n1 * sv_n + (size_t)g * sv_h + sch * 8);
       }
-      kreg[i] = kv;  // rows past the end are ZERO (P = 0 times garbage must not make NaN)
-      vreg[i] = vv;
     }
   };
   auto lstore = [&](int buf) {
     if (stage_active) {
       char* kb = smem + buf * 2 * PF_TILE_BYTES;
       char* vb = kb + PF_TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int jj = srow + 32 * i;
-        *reinterpret_cast<uint4*>(kb + k_off(jj, sch)) = kreg[i];
-        *reinterpret_cast<uint4*>(vb + v_off(jj, sch)) = vreg[i];
-      }
+      *reinterpret_cast<uint4*>(kb + k_off(srow, sch)) = kr0;
+      *reinterpret_cast<uint4*>(kb + k_off(srow + 32, sch)) = kr1;
+      *reinterpret_cast<uint4*>(vb + v_off(srow, sch)) = vr0;
+      *reinterpret_cast<uint4*>(vb + v_off(srow + 32, sch)) = vr1;
     }
   };
 
@@ -162,56 +158,68 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   const int li = lane & 15;
   const int tq = li >> 2, tp = li & 3;
 
+  // ---- main loop: one 64-key tile per iteration ------------------------------------------------------------------
+  // Global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after
+  // them; one barrier per tile.  (A half-tile stagger of waves 4-7 against waves 0-3 - so that SIMD partners sit
+  // in opposite MFMA / VALU phases - was built with 3 LDS buffers and two barriers per tile and measured SLOWER
+  // (760 vs 842 TFLOP/s at 32K): the second barrier costs more than the overlap returns.)
+  kr0 = kr1 = vr0 = vr1 = make_uint4(0, 0, 0, 0);
   gload(0);
   lstore(0);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) gload(t + 1);
-
+    const int buf = (dbg & 1) ? 0 : (t & 1);
+    if (t + 1 < ntiles && !(dbg & 1)) gload(t + 1);
     const char* kb = smem + buf * 2 * PF_TILE_BYTES;
     const char* vb = kb + PF_TILE_BYTES;
 
-    // ---- S^T = K Q^T : two 32-key blocks --------------------------------------------------------------------
+    // ---- S^T = K Q^T, two 32-key blocks ------------------------------------------------------------------------
     f32x16 sacc[2];
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sacc[kb2][i] = 0.f;
+      if (!(dbg & 8)) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const uint4 a = *reinterpret_cast<const uint4*>(kb + k_off(kb2 * 32 + r, 2 * s + h));
-        sacc[kb2] = mfma32<T>(__builtin_bit_cast(s16x8, a), qf[s], sacc[kb2]);
+        for (int s = 0; s < KS; ++s) {
+          const uint4 a = *reinterpret_cast<const uint4*>(kb + k_off(kb2 * 32 + r, 2 * s + h));
+          sacc[kb2] = mfma32<T>(__builtin_bit_cast(s16x8, a), qf[s], sacc[kb2]);
+        }
       }
     }
-
-    // ---- masking + online softmax (lane = one query; rows of the accumulator = keys) -----------------------
     const bool cached = t < ntc;
     const int j0 = cached ? t * PF_KT : (t - ntc) * PF_KT;
     const int count = cached ? min(PF_KT, Lc - j0) : min(PF_KT, la_vis - j0);
     const bool need_mask = count < PF_KT || (!cached && j0 + PF_KT - 1 > m0);  // wave-uniform
-    float x[2][16];
+    // max over the RAW logits (scale > 0 commutes with max), then p = exp2(s*c - m*c): one FMA per logit
     float mx = -INFINITY;
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float val = sacc[kb2][i] * scale_log2e;
         if (need_mask) {
           const int kk = kb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
           const bool vis = kk < count && (cached || (j0 + kk) <= tok);
-          val = vis ? val : -INFINITY;
+          sacc[kb2][i] = vis ? sacc[kb2][i] : -INFINITY;
         }
-        x[kb2][i] = val;
-        mx = fmaxf(mx, val);
+        mx = fmaxf(mx, sacc[kb2][i]);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
     const float m_new = fmaxf(m_run, mx);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const bool grew = m_new > m_run;  // per query; rescale O only when some query of the wave saw a new max
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
     m_run = m_new;
+    if (__any(grew)) {  // exact: alpha == 1 for every lane otherwise (T13 with threshold 0)
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+    }
+
+    // ---- P = exp2(S c - m), packed to the model dtype; O^T += V^T P^T ------------------------------------------
     float psum = 0.f;
     s16x8 pf[4];
 #pragma unroll
@@ -221,8 +229,12 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
         uint32_t w[4];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-          const float p0 = __builtin_amdgcn_exp2f(x[kb2][8 * s2 + 2 * jp] - m_safe);
-          const float p1 = __builtin_amdgcn_exp2f(x[kb2][8 * s2 + 2 * jp + 1] - m_safe);
+          float p0 = fmaf(sacc[kb2][8 * s2 + 2 * jp], scale_log2e, -m_safe);
+          float p1 = fmaf(sacc[kb2][8 * s2 + 2 * jp + 1], scale_log2e, -m_safe);
+          if (!(dbg & 2)) {
+            p0 = __builtin_amdgcn_exp2f(p0);
+            p1 = __builtin_amdgcn_exp2f(p1);
+          }
           w[jp] = pack2<T>(p0, p1);
           // row sum from the fp32 probabilities, P itself rounded to the model dtype (reference :398-400)
           psum += p0 + p1;
@@ -231,29 +243,26 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
       }
     }
     l_run = l_run * alpha + psum;
+    if (!(dbg & 4)) {
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+      for (int ks = 0; ks < 4; ++ks) {
+        // key rows of this k-step start at (ks>>1)*32 + (ks&1)*16: a multiple of 16 rows, so it does not touch
+        // the swizzle bits ((row&3), (row>>2)&3) and is a pure byte offset
 #pragma unroll
-      for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
-
-    // ---- O^T += V^T P^T : 4 k-steps of 16 keys, DB blocks of 32 dims --------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int r0 = (ks >> 1) * 32 + (ks & 1) * 16 + 4 * (gi >> 1);  // first key row of this lane group's block
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const int c0 = (db * 2 + (gi & 1)) * 2;  // first 16-byte chunk of the block's 16 columns
-        const uint32_t a0 = v_off(r0 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
-        const uint32_t a1 = v_off(r0 + 8 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a1));
-        const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        oacc[db] = mfma32<T>(a, pf[ks], oacc[db]);
+        for (int db = 0; db < DB; ++db) {
+          const int r0 = (ks >> 1) * 32 + (ks & 1) * 16 + 4 * (gi >> 1);  // first key row of this lane group's block
+          const int c0 = (db * 2 + (gi & 1)) * 2;                         // first 16-byte chunk of its 16 columns
+          const uint32_t a0 = v_off(r0 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
+          const uint32_t a1 = v_off(r0 + 8 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a1));
+          const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[db] = mfma32<T>(a, pf[ks], oacc[db]);
+        }
       }
     }
-
-    if (t + 1 < ntiles) lstore(buf ^ 1);
-    __syncthreads();
+    if (t + 1 < ntiles && !(dbg & 1)) lstore(buf ^ 1);
+    if (!(dbg & 16)) __syncthreads();
   }
 
   // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ------------------------
@@ -286,6 +295,8 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   }
 }
 
+static int g_pf_dbg = 0;  // timing experiments only (tools/microbench.py): skip phases, results are garbage
+
 template <typename T, int D, int G>
 static int launch_prefill(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                           int64_t sv_n, int64_t sv_h, const void* kc, const void* vc, void* out, const int* seq_lens,
@@ -301,7 +312,7 @@ static int launch_prefill(const void* q, const void* k, const void* v, int64_t s
   }
   hipLaunchKernelGGL(kern, dim3(nqt * B * HKV), dim3(PF_THREADS), PF_SMEM, st, (const uint16_t*)q, (const uint16_t*)k,
                      (const uint16_t*)v, sq_n, sk_n, sk_h, sv_n, sv_h, (const uint16_t*)kc, (const uint16_t*)vc,
-                     (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP, scale * 1.4426950408889634f);
+                     (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP, scale * 1.4426950408889634f, g_pf_dbg);
   return check_launch();
 }
 
@@ -326,6 +337,8 @@ static int prefill_dispatch_g(int G, const void* q, const void* k, const void* v
 }  // namespace cvllm
 
 using namespace cvllm;
+
+extern "C" void cvllm_debug_set_prefill(int v) { cvllm::g_pf_dbg = v; }
 
 extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n,
                                   int64_t sk_h, int64_t sv_n, int64_t sv_h, const void* k_cache, const void* v_cache,
