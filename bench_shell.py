@@ -56,6 +56,8 @@ def shell():
         L.shell_add_rmsnorm.argtypes = [P, P, P, P, I, I, F, P]
         L.shell_rope.argtypes = [P, L64, P, P, P, P, P, I, I, I, F, P]
         L.shell_silu_mul.argtypes = [P, P, ctypes.c_long, I, P]
+        L.shell_gemv.argtypes = [P, P, P, I, I, I, P]
+        L.shell_gemv.restype = I
         for f in (L.shell_add_rmsnorm, L.shell_rope, L.shell_silu_mul):
             f.restype = None
         _shell = L
@@ -64,6 +66,20 @@ def shell():
 
 def _st():
     return torch.cuda.current_stream().cuda_stream
+
+
+USE_SHELL_GEMV = True
+
+
+def linear(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x [N, K] @ w[M, K]^T.  Prefill (N large): hipBLASLt through torch.matmul.  Decode (N <= 4): a plain
+    bandwidth-bound GEMV kernel of the shell (hipBLASLt's M=1 kernels reach ~3.9 TB/s on these shapes)."""
+    N, K = x.shape
+    if USE_SHELL_GEMV and N <= 4 and K * N * 2 <= 65536 and x.is_contiguous() and w.is_contiguous():
+        y = torch.empty((N, w.shape[0]), dtype=x.dtype, device=x.device)
+        if shell().shell_gemv(w.data_ptr(), x.data_ptr(), y.data_ptr(), N, w.shape[0], K, _st()) == 0:
+            return y
+    return torch.matmul(x, w.t())
 
 
 @dataclass
@@ -144,7 +160,7 @@ class ModelShell:
         for li, L in enumerate(self.layers):
             S.shell_add_rmsnorm(h.data_ptr(), None if delta is None else delta.data_ptr(), L["n1"].data_ptr(),
                                 x.data_ptr(), N, H, cfg.rms_eps, _st())
-            qkv = torch.matmul(x, L["wqkv"].t())
+            qkv = linear(x, L["wqkv"])
             q_pre = qkv[:, : self.qsz].view(N, cfg.heads, D)
             k_pre = qkv[:, self.qsz : self.qsz + self.kvsz].view(N, cfg.kv_heads, D)
             v = qkv[:, self.qsz + self.kvsz :].view(N, cfg.kv_heads, D)  # strided view, like the reference
@@ -167,14 +183,14 @@ class ModelShell:
             if compress:
                 scores = apply_postrope_compression(q, k, v, scores, ctx)
             o = self.attn[li](q, k, v, scores)
-            delta = torch.matmul(o.view(N, self.qsz), L["wo"].t())
+            delta = linear(o.view(N, self.qsz), L["wo"])
             S.shell_add_rmsnorm(h.data_ptr(), delta.data_ptr(), L["n2"].data_ptr(), x.data_ptr(), N, H, cfg.rms_eps,
                                 _st())
-            gu = torch.matmul(x, L["wgu"].t())
+            gu = linear(x, L["wgu"])
             act = torch.empty((N, I), dtype=h.dtype, device=h.device)
             S.shell_silu_mul(gu.data_ptr(), act.data_ptr(), N, I, _st())
             del gu
-            delta = torch.matmul(act, L["wd"].t())
+            delta = linear(act, L["wd"])
             del act
         if last_rows is not None:
             h = h.index_select(0, last_rows)
@@ -182,7 +198,7 @@ class ModelShell:
         xf = torch.empty_like(h)
         S.shell_add_rmsnorm(h.data_ptr(), delta.data_ptr(), self.final_norm.data_ptr(), xf.data_ptr(), h.shape[0], H,
                             cfg.rms_eps, _st())
-        logits = torch.matmul(xf, self.lm_head.t())
+        logits = linear(xf, self.lm_head)
         return logits.argmax(dim=-1)  # temperature 0
 
     # ---- generate: prefill (+ compression overlapped on the store stream) then HIP-graph decode ----------------

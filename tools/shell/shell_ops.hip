@@ -104,6 +104,78 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
   }
 }
 
+// y[b, n] = sum_k W[n, k] * x[b, k]   (bf16 in/out, fp32 accumulate), B <= 4 rows of x: the decode-step GEMV.
+// Bandwidth bound on W (read once per step -> non-temporal loads).  A wave owns RPW rows at a time with all of
+// their loads in flight; x sits in LDS (read as 16-byte chunks, lane-consecutive = conflict free).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf162_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf162_t, a), __builtin_bit_cast(bf162_t, b), c, false);
+}
+template <int B, int RPW>
+__global__ __launch_bounds__(256) void gemv_kernel(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x,
+                                                   uint16_t* __restrict__ y, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_x[];  // [B][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid * 8; i < B * K; i += 256 * 8) *reinterpret_cast<uint4*>(s_x + i) = *reinterpret_cast<const uint4*>(x + i);
+  __syncthreads();
+  const int nchunk = K / 8;  // 16-byte chunks per row
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < N; row0 += gridDim.x * 4 * RPW) {
+    float acc[RPW][B];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+      u32x4_t w[RPW];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, N - 1);
+        w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W + (size_t)row * K + c * 8));
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(s_x + b * K + c * 8);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          float a = acc[r][b];
+          a = dot2bf(w[r].x, xv.x, a);
+          a = dot2bf(w[r].y, xv.y, a);
+          a = dot2bf(w[r].z, xv.z, a);
+          a = dot2bf(w[r].w, xv.w, a);
+          acc[r][b] = a;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float t = wave_sum(acc[r][b]);
+        if (lane == 0 && row0 + r < N) y[(size_t)b * N + row0 + r] = f2bf(t);
+      }
+  }
+}
+
+extern "C" int shell_gemv(const void* W, const void* x, void* y, int B, int N, int K, void* stream) {
+  if (K % 8 || B < 1 || B > 4) return -1;
+  const size_t smem = (size_t)B * K * 2;
+  if (smem > 64 * 1024) return -1;
+  constexpr int RPW = 4;
+  int blocks = (N + 4 * RPW - 1) / (4 * RPW);
+  if (blocks > 2048) blocks = 2048;
+#define GV(B_) hipLaunchKernelGGL((gemv_kernel<B_, RPW>), dim3(blocks), dim3(256), smem, (hipStream_t)stream, \
+                                  (const uint16_t*)W, (const uint16_t*)x, (uint16_t*)y, N, K)
+  switch (B) {
+    case 1: GV(1); break;
+    case 2: GV(2); break;
+    case 3: GV(3); break;
+    default: GV(4); break;
+  }
+#undef GV
+  return 0;
+}
+
 extern "C" void shell_add_rmsnorm(void* h, const void* delta, const void* w, void* y, int N, int C, float eps,
                                   void* stream) {
   if (N > 0)
