@@ -31,7 +31,8 @@ SIGNATURES = {
     "cvllm_store_all_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvllm_prefill_attn": (_I, [_P, _P, _P, _L, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                                 _I, _I, _I, _F, _I, _P]),
-    "cvllm_zscore_segments": (_I, [_P, _I, _P, _I, _I, _P, _I, _F, _P, _I, _I, _P]),
+    "cvllm_zscore_workspace_bytes": (_Z, [_I]),
+    "cvllm_zscore_segments": (_I, [_P, _I, _P, _I, _I, _P, _I, _F, _P, _I, _I, _P, _Z, _P]),
     "cvllm_chunk_attn_mass": (_I, [_P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "cvllm_leverage_workspace_bytes": (_Z, [_I, _I, _I]),
     "cvllm_leverage_scores": (_I, [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),

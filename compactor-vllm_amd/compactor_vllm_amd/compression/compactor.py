@@ -88,10 +88,14 @@ def zscore_segments_(x: torch.Tensor, cu: torch.Tensor, accum: torch.Tensor | No
     `+ blend * accum`, then rows in prot_ranges [n,2] <- +inf."""
     assert x.is_contiguous() and x.ndim == 2
     n_seg = cu.numel() - 1
-    st = _lib.lib().cvllm_zscore_segments(
+    L = _lib.lib()
+    ws_bytes = L.cvllm_zscore_workspace_bytes(n_seg)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=x.device)
+    st = L.cvllm_zscore_segments(
         x.data_ptr(), _lib.score_dtype_code(x.dtype), cu.data_ptr(), n_seg, x.shape[1],
         _lib.ptr(accum), 0 if accum is None else _lib.score_dtype_code(accum.dtype), float(blend),
-        _lib.ptr(prot_ranges), 0 if prot_ranges is None else int(prot_ranges.shape[0]), x.shape[0], _lib.stream(),
+        _lib.ptr(prot_ranges), 0 if prot_ranges is None else int(prot_ranges.shape[0]), x.shape[0],
+        ws.data_ptr(), ws_bytes, _lib.stream(),
     )
     _lib.check(st, "cvllm_zscore_segments")
     return x

@@ -275,7 +275,7 @@ struct VmWait;
   };
 CVLLM_VMWAIT(0) CVLLM_VMWAIT(8) CVLLM_VMWAIT(12) CVLLM_VMWAIT(16) CVLLM_VMWAIT(24) CVLLM_VMWAIT(32)
 
-constexpr int DEC_PGREGS = 4;       // page ids cached in registers: 4 x 64 pages per split
+constexpr int DEC_PGREGS = 8;       // page ids cached in registers: 8 x 64 pages
 constexpr int DEC_MAX_SPLITS = 256;
 
 template <typename T, int D, int G, int NW, int NL, int R>
@@ -315,6 +315,20 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   const int bt = bmap[b];
   const int lidx = lens_by_row ? bt * HKV + h : bh;
   const bool append = key_new != nullptr && bt != reserved;
+  // Page ids: when the whole row of the page table fits the register cache (NLP <= 512 pages = 64K rows at
+  // PS 128) it is loaded by ABSOLUTE logical page, which depends on batch_mapping only - so it is in flight
+  // together with the length load instead of behind it (one dependent HBM/L2 round trip less before the
+  // first K/V byte).  Longer tables fall back to loading just the split's window once L is known.
+  const bool pg_abs = NLP <= 64 * DEC_PGREGS;  // uniform
+  const int* pt = page_table + ((size_t)bt * HKV + h) * NLP;
+  int pgreg[DEC_PGREGS];
+  if (pg_abs) {
+#pragma unroll
+    for (int j = 0; j < DEC_PGREGS; ++j) {
+      const int i = lane + 64 * j;
+      pgreg[j] = i < NLP ? pt[i] : 0;
+    }
+  }
   const int L_old = seq_lens[lidx];
   const int L = (key_new != nullptr && bt == reserved) ? 0 : L_old + (append ? 1 : 0);
 
@@ -329,15 +343,16 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   float* pl = part_lse + (size_t)(b * S + s) * HQ + h * G;
 
   if (!empty) {
-    const int* pt = page_table + ((size_t)bt * HKV + h) * NLP;
     const int lp0 = start / PS;
-    const int nlp = (end - 1) / PS - lp0 + 1;  // <= 64 * DEC_PGREGS (checked on the host)
-    int pgreg[DEC_PGREGS];
+    if (!pg_abs) {
+      const int nlp = (end - 1) / PS - lp0 + 1;  // <= 64 * DEC_PGREGS (checked on the host)
 #pragma unroll
-    for (int j = 0; j < DEC_PGREGS; ++j) {
-      const int i = lane + 64 * j;
-      pgreg[j] = i < nlp ? pt[lp0 + i] : 0;
+      for (int j = 0; j < DEC_PGREGS; ++j) {
+        const int i = lane + 64 * j;
+        pgreg[j] = i < nlp ? pt[lp0 + i] : 0;
+      }
     }
+    const int pg_bias = pg_abs ? lp0 : 0;  // page_of() takes a page index relative to the split
     uint4 qf[G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -371,7 +386,8 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     const uint32_t lane_off = lane * 16;
 
-    auto page_of = [&](int lpi) {
+    auto page_of = [&](int lpi_rel) {
+      const int lpi = lpi_rel + pg_bias;
       int pg = __builtin_amdgcn_readlane(pgreg[0], lpi & 63);
 #pragma unroll
       for (int j = 1; j < DEC_PGREGS; ++j)
@@ -742,8 +758,8 @@ static int decode_common(DecodeArgs a, int HQ, int D, int dtype, size_t workspac
   if (HQ % a.HKV != 0 || a.S > DEC_MAX_SPLITS) return CVLLM_ERR_SHAPE;
   // a unit of (64/(D/8))*4 rows must not straddle a page; the reference requires PAGE_SIZE % 32 == 0 (:80)
   if (a.PS <= 0 || a.PS % 32 != 0) return CVLLM_ERR_SHAPE;
-  // the ring kernel keeps a split's page ids in 4 VGPRs (256 pages): rows per split <= 256 * page_size
-  if ((a.NLP + a.S - 1) / a.S + 1 > 64 * DEC_PGREGS) return CVLLM_ERR_SHAPE;
+  // the ring kernel keeps page ids in 8 VGPRs (512 pages): the whole row, or else one split's window
+  if (a.NLP > 64 * DEC_PGREGS && (a.NLP + a.S - 1) / a.S + 1 > 64 * DEC_PGREGS) return CVLLM_ERR_SHAPE;
   if (a.S > 1 && (!a.ws || workspace_bytes < cvllm_decode_workspace_bytes(a.B, HQ, D, a.S))) return CVLLM_ERR_WORKSPACE;
   if (a.key_new && D > 128) return CVLLM_ERR_SHAPE;  // fused append exists in the ring kernel only
   const int G = HQ / a.HKV;

@@ -41,16 +41,21 @@ __device__ __forceinline__ void st_score(void* p, size_t i, float v) {
 }
 
 constexpr int ZS_T = 1024;
-template <int DT, int ADT>
-__global__ __launch_bounds__(ZS_T) void zscore_kernel(void* __restrict__ x, const int* __restrict__ cu, int H,
-                                                      const void* __restrict__ accum, float blend) {
+constexpr int ZS_MAXTILES = 32;
+// Two kernels, both grid (segment, tile): (1) per-tile partial sum / sum of squares, (2) every tile folds the
+// partials of its segment IN TILE ORDER (deterministic: no float atomics), then normalises its own slice.
+template <int DT>
+__global__ __launch_bounds__(ZS_T) void zscore_partial_kernel(const void* __restrict__ x, const int* __restrict__ cu,
+                                                              int H, int T, float* __restrict__ part) {
   __shared__ float s_a[ZS_T / 64], s_b[ZS_T / 64];
-  const int seg = blockIdx.x;
+  const int seg = blockIdx.x, tile = blockIdx.y;
   const size_t beg = (size_t)cu[seg] * H, end = (size_t)cu[seg + 1] * H;
-  if (end <= beg) return;
+  const size_t n = end > beg ? end - beg : 0;
+  const size_t per = (n + T - 1) / T;
+  const size_t lo = beg + per * tile, hi = min(lo + per, end);
   const int tid = threadIdx.x;
   float sum = 0.f, sq = 0.f;
-  for (size_t i = beg + tid; i < end; i += ZS_T) {
+  for (size_t i = lo + tid; i < hi; i += ZS_T) {
     const float v = ld_score<DT>(x, i);
     sum += v;
     sq += v * v;
@@ -62,18 +67,38 @@ __global__ __launch_bounds__(ZS_T) void zscore_kernel(void* __restrict__ x, cons
     s_b[tid >> 6] = sq;
   }
   __syncthreads();
-  sum = 0.f;
-  sq = 0.f;
+  if (tid == 0) {
+    sum = 0.f;
+    sq = 0.f;
 #pragma unroll
-  for (int w = 0; w < ZS_T / 64; ++w) {
-    sum += s_a[w];
-    sq += s_b[w];
+    for (int w = 0; w < ZS_T / 64; ++w) {
+      sum += s_a[w];
+      sq += s_b[w];
+    }
+    part[((size_t)seg * T + tile) * 2] = sum;
+    part[((size_t)seg * T + tile) * 2 + 1] = sq;
+  }
+}
+
+template <int DT, int ADT>
+__global__ __launch_bounds__(ZS_T) void zscore_apply_kernel(void* __restrict__ x, const int* __restrict__ cu, int H,
+                                                            int T, const float* __restrict__ part,
+                                                            const void* __restrict__ accum, float blend) {
+  const int seg = blockIdx.x, tile = blockIdx.y;
+  const size_t beg = (size_t)cu[seg] * H, end = (size_t)cu[seg + 1] * H;
+  if (end <= beg) return;
+  float sum = 0.f, sq = 0.f;
+  for (int t = 0; t < T; ++t) {
+    sum += part[((size_t)seg * T + t) * 2];
+    sq += part[((size_t)seg * T + t) * 2 + 1];
   }
   const float cnt = (float)(end - beg);
   const float mean = sum / cnt;
   const float var = fmaxf(sq / cnt - mean * mean, 0.f);  // biased, clamped, NO epsilon (compactor.py:258-260)
   const float invstd = 1.0f / sqrtf(var);
-  for (size_t i = beg + tid; i < end; i += ZS_T) {
+  const size_t per = (end - beg + T - 1) / T;
+  const size_t lo = beg + per * tile, hi = min(lo + per, end);
+  for (size_t i = lo + threadIdx.x; i < hi; i += ZS_T) {
     float v = (ld_score<DT>(x, i) - mean) * invstd;
     if (accum) v += blend * ld_score<ADT>(accum, i);
     st_score<DT>(x, i, v);
@@ -534,16 +559,32 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
 using namespace cvllm;
 
 // ---------------------------------------------------------------------------------------------------------
+extern "C" size_t cvllm_zscore_workspace_bytes(int n_segments) {
+  return n_segments > 0 ? (size_t)n_segments * ZS_MAXTILES * 2 * sizeof(float) : 0;
+}
+
 extern "C" int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
                                      const void* accum, int accum_dtype, float blend, const int32_t* prot_ranges,
-                                     int n_ranges, int total_rows, cvllm_stream_t stream) {
+                                     int n_ranges, int total_rows, void* workspace, size_t workspace_bytes,
+                                     cvllm_stream_t stream) {
   if (!x || (n_segments > 0 && !cu) || H <= 0 || n_segments < 0 || n_ranges < 0) return CVLLM_ERR_ARG;
   if (score_dtype < 0 || score_dtype > 2 || (accum && (accum_dtype < 0 || accum_dtype > 2))) return CVLLM_ERR_SHAPE;
   if (n_ranges > 0 && !prot_ranges) return CVLLM_ERR_ARG;
+  if (n_segments > 0 && (!workspace || workspace_bytes < cvllm_zscore_workspace_bytes(n_segments)))
+    return CVLLM_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (n_segments > 0) {
+    // tiles per segment from the AVERAGE segment size (host ints only): ~4096 elements per tile
+    long avg = ((long)total_rows / n_segments) * H;
+    int T = (int)((avg + 4095) / 4096);
+    T = T < 1 ? 1 : (T > ZS_MAXTILES ? ZS_MAXTILES : T);
+    float* part = (float*)workspace;
+    dim3 grid(n_segments, T);
+    if (score_dtype == 0) hipLaunchKernelGGL((zscore_partial_kernel<0>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part);
+    else if (score_dtype == 1) hipLaunchKernelGGL((zscore_partial_kernel<1>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part);
+    else hipLaunchKernelGGL((zscore_partial_kernel<2>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part);
 #define ZS(DT, ADT) \
-  hipLaunchKernelGGL((zscore_kernel<DT, ADT>), dim3(n_segments), dim3(ZS_T), 0, st, x, cu, H, accum, blend)
+  hipLaunchKernelGGL((zscore_apply_kernel<DT, ADT>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part, accum, blend)
     const int adt = accum ? accum_dtype : 2;
     switch (score_dtype * 3 + adt) {
       case 0: ZS(0, 0); break;

@@ -111,11 +111,13 @@ int cvllm_prefill_attn(const void* q, const void* k, const void* v, int64_t sq_n
  * Optional fused epilogue (compactor.py:586-598): x = z(x) + blend*accum (accum_dtype coded as
  * score_dtype, accum may be NULL), then the rows of prot_ranges (int32 [n_ranges,2] = [lo,hi)
  * row ranges, may be NULL) <- +inf.  The python-slice semantics of the reference's fills
- * (quirk Q9) are resolved to explicit ranges by the host wrapper.                            */
+ * (quirk Q9) are resolved to explicit ranges by the host wrapper.  Long segments are reduced by
+ * several workgroups through per-tile partials in `workspace` (fixed fold order: deterministic). */
+size_t cvllm_zscore_workspace_bytes(int n_segments);
 int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
                           const void* accum, int accum_dtype, float blend,
                           const int32_t* prot_ranges, int n_ranges, int total_rows,
-                          cvllm_stream_t stream);
+                          void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
 
 /* ---- a7: Compactor post-RoPE chunked non-causal attention mass -------------------------------
  * replaces compression/compactor.py:338-486 _non_causal_attn_kernel (+ wrapper :489-580).
