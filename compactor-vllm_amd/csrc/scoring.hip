@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void chunk_mass_kernel(const uint16_t* __restr
 
 // =====================================================================================================
 // a5: leverage scores.  K1: X = K_h PHI (MFMA, fp32 out).  K2: per (chunk, head): centre, Gram + reg*I,
-// Cholesky, Ginv, score_i = xc_i^T Ginv xc_i  (all fp32).
+// Cholesky G = L L^T, score_i = xc_i^T G^-1 xc_i = ||L^-1 xc_i||^2  (all fp32).
 // =====================================================================================================
 constexpr int LV_KMAX = 64;  // sketch columns padded to two 32-wide MFMA blocks
 template <typename T, int D>
@@ -295,8 +295,7 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
                                                              float reg) {
   __shared__ float s_mean[LV_KD];
   __shared__ float s_G[LV_KD * LV_LD];    // Gram -> Cholesky factor L (lower)
-  __shared__ float s_Li[LV_KD * LV_LD];   // L^-1 (lower)
-  __shared__ float s_Gi[LV_KD * LV_LD];   // G^-1
+  __shared__ float s_Li[LV_KD];           // 1 / L[k][k]
   __shared__ float s_tile[64 * LV_LD];    // 64 centred rows
   const int cidx = blockIdx.x / HKV, hh = blockIdx.x % HKV;
   const int beg = chunk_cu[cidx], end = chunk_cu[cidx + 1];
@@ -348,49 +347,48 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
     s_G[a * LV_LD + bcol] = gacc[j] + (a == bcol ? reg : 0.f);
   }
   __syncthreads();
-  // Cholesky (right-looking), whole workgroup, barrier per column
-  for (int j = 0; j < LV_KD; ++j) {
-    const float djj = sqrtf(s_G[j * LV_LD + j]);
-    __syncthreads();
-    if (tid == 0) s_G[j * LV_LD + j] = djj;
-    if (tid > j && tid < LV_KD) s_G[tid * LV_LD + j] /= djj;
-    __syncthreads();
-    for (int e = tid; e < LV_KD * LV_KD; e += 256) {
-      const int i = e / LV_KD, kcol = e % LV_KD;
-      if (kcol > j && i >= kcol) s_G[i * LV_LD + kcol] -= s_G[i * LV_LD + j] * s_G[kcol * LV_LD + j];
+  // Cholesky G = L L^T by ONE wave, entirely in registers: lane i owns row i (48 floats, compile-time indexed by
+  // full unrolling); column j of L is broadcast to the other lanes with v_readlane.  ~2.3K instructions, no barrier,
+  // no LDS round trip per step (a barrier-per-column workgroup version took ~10x longer).
+  if (tid < 64) {
+    const int lane = tid;
+    const int rown = lane < LV_KD ? lane : LV_KD - 1;
+    float a[LV_KD];
+#pragma unroll
+    for (int cc = 0; cc < LV_KD; ++cc) a[cc] = s_G[rown * LV_LD + cc];
+#pragma unroll
+    for (int j = 0; j < LV_KD; ++j) {
+      const float d = sqrtf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j)));
+      a[j] = (lane == j) ? d : a[j] / d;  // rows i > j: L[i][j]; rows i < j hold don't-care values
+#pragma unroll
+      for (int kk = j + 1; kk < LV_KD; ++kk) {
+        const float lkj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), kk));
+        a[kk] = fmaf(-a[j], lkj, a[kk]);  // A[i][k] -= L[i][j] L[k][j]   (meaningful for i >= k)
+      }
     }
-    __syncthreads();
-  }
-  // L^-1 by forward substitution, one column per thread
-  if (tid < LV_KD) {
-    const int ccol = tid;
-    for (int i = 0; i < LV_KD; ++i) {
-      float t = (i == ccol) ? 1.f : 0.f;
-      for (int kk = ccol; kk < i; ++kk) t -= s_G[i * LV_LD + kk] * s_Li[kk * LV_LD + ccol];
-      s_Li[i * LV_LD + ccol] = (i < ccol) ? 0.f : t / s_G[i * LV_LD + i];
+    if (lane < LV_KD) {
+#pragma unroll
+      for (int cc = 0; cc < LV_KD; ++cc) s_G[lane * LV_LD + cc] = a[cc];  // lower triangle incl. diagonal = L
     }
   }
   __syncthreads();
-  // G^-1 = L^-T L^-1
-  for (int e = tid; e < LV_KD * LV_KD; e += 256) {
-    const int a = e / LV_KD, bcol = e % LV_KD;
-    float t = 0.f;
-    for (int kk = max(a, bcol); kk < LV_KD; ++kk) t = fmaf(s_Li[kk * LV_LD + a], s_Li[kk * LV_LD + bcol], t);
-    s_Gi[a * LV_LD + bcol] = t;
-  }
+  if (tid < LV_KD) s_Li[tid] = 1.0f / s_G[tid * LV_LD + tid];  // reciprocal diagonal
   __syncthreads();
-  // scores: one row per thread
+  // score_i = || L^-1 xc_i ||^2 by forward substitution, one row per thread; L is read from LDS at compile-time
+  // offsets (every thread reads the same address: broadcast, conflict free)
   for (int i = tid; i < L; i += 256) {
-    float xc[LV_KD];
+    float y[LV_KD];
 #pragma unroll
-    for (int cc = 0; cc < LV_KD; ++cc) xc[cc] = Xh[(size_t)i * LV_KD + cc] - s_mean[cc];
+    for (int cc = 0; cc < LV_KD; ++cc) y[cc] = Xh[(size_t)i * LV_KD + cc] - s_mean[cc];
     float sc = 0.f;
-    for (int a = 0; a < LV_KD; ++a) {
-      float t = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < LV_KD; ++cc) t = fmaf(s_Gi[a * LV_LD + cc], xc[cc], t);
-      // xc[a] with a runtime index would spill: recompute the a-th component from memory instead
-      sc = fmaf(t, Xh[(size_t)i * LV_KD + a] - s_mean[a], sc);
+    for (int kk = 0; kk < LV_KD; ++kk) {
+      float t = y[kk];
+#pragma unroll
+      for (int m = 0; m < kk; ++m) t = fmaf(-s_G[kk * LV_LD + m], y[m], t);
+      t *= s_Li[kk];
+      y[kk] = t;
+      sc = fmaf(t, t, sc);
     }
     scores[(size_t)(beg + i) * HKV + hh] = fmaxf(sc, 0.f);
   }

@@ -28,6 +28,9 @@ __device__ __forceinline__ uint32_t order_key(float x) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending uint order == ascending float order
 }
 
+constexpr int SEL_E = 4;  // elements per thread per iteration: 4 independent loads in flight (the loops are
+                          // L2-latency bound with one), thread t owns the CONSECUTIVE indices base + 4t .. +3
+
 // Exact selection of the r-th largest (1-based, 1 <= r <= n) ordered key among n strided floats.
 // Returns the key value v and `quota` = how many elements equal to v belong to the top r
 // (count(key > v) = r - quota).  All SEL_T threads must call; hist is LDS [256], s_state LDS [2].
@@ -40,27 +43,41 @@ __device__ void radix_select_desc(const float* __restrict__ base, int stride, in
     const int shift = 24 - 8 * pass;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += SEL_T) {
-      const int i = i0 + tid;
-      bool act = false;
-      uint32_t digit = 0;
-      if (i < n) {
-        const uint32_t k = order_key(base[(size_t)i * stride]);
-        act = pass == 0 || (k >> (shift + 8)) == prefix;
-        digit = (k >> shift) & 0xffu;
+    float nxt[SEL_E];  // software prefetch: the next iteration's loads are in flight while this one is binned
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) {
+      const int i = tid * SEL_E + e;
+      nxt[e] = i < n ? base[(size_t)i * stride] : 0.f;
+    }
+    for (int i0 = 0; i0 < n; i0 += SEL_T * SEL_E) {
+      uint32_t key[SEL_E];
+      bool in[SEL_E];
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        in[e] = i0 + tid * SEL_E + e < n;
+        key[e] = order_key(nxt[e]);
+        const int i2 = i0 + SEL_T * SEL_E + tid * SEL_E + e;
+        nxt[e] = i2 < n ? base[(size_t)i2 * stride] : 0.f;
       }
-      // wave-aggregated histogram: a few leader rounds soak up the heavy bins, the rest use LDS atomics
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        bool act = in[e] && (pass == 0 || (key[e] >> (shift + 8)) == prefix);
+        const uint32_t digit = (key[e] >> shift) & 0xffu;
+        // wave-aggregated histogram: each leader round retires one distinct digit of the wave with ONE atomic
+        // (z-scored data puts a wave's 64 keys into a handful of top-byte bins: same-address LDS atomics would
+        // serialise ~30-way); anything still active after 12 rounds falls back to per-lane atomics
 #pragma unroll 1
-      for (int round = 0; round < 4; ++round) {
-        const unsigned long long am = __ballot(act);
-        if (am == 0ull) break;
-        const int leader = __ffsll((long long)am) - 1;
-        const uint32_t ld = __shfl((int)digit, leader, 64);
-        const unsigned long long mm = __ballot(act && digit == ld);
-        if ((tid & 63) == leader) atomicAdd(&hist[ld], (uint32_t)__popcll(mm));
-        if (digit == ld) act = false;
+        for (int round = 0; round < 12; ++round) {
+          const unsigned long long am = __ballot(act);
+          if (am == 0ull) break;
+          const int leader = __ffsll((long long)am) - 1;
+          const uint32_t ld = __shfl((int)digit, leader, 64);
+          const unsigned long long mm = __ballot(act && digit == ld);
+          if ((tid & 63) == leader) atomicAdd(&hist[ld], (uint32_t)__popcll(mm));
+          if (digit == ld) act = false;
+        }
+        if (act) atomicAdd(&hist[digit], 1u);
       }
-      if (act) atomicAdd(&hist[digit], 1u);
     }
     __syncthreads();
     if (tid < 64) {  // one wave walks the 256 bins from the top: 4 bins per lane, lane 0 owns the largest
@@ -96,12 +113,16 @@ __device__ void radix_select_desc(const float* __restrict__ base, int stride, in
   quota_out = remaining;
 }
 
-// block-wide exclusive scan of a 0/1 flag over SEL_T threads; returns exclusive prefix, total via s_tot
-__device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_wsum, int& total) {
+// block-wide exclusive scan of a small per-thread count over SEL_T threads (thread order = index order)
+__device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long bal = __ballot(flag);
-  const int before = __popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) s_wsum[wave] = __popcll(bal);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
   __syncthreads();
   int woff = 0, tot = 0;
 #pragma unroll
@@ -112,7 +133,7 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* s_wsum, int&
   }
   __syncthreads();
   total = tot;
-  return woff + before;
+  return woff + incl - cnt;
 }
 
 // kernel 1: one workgroup per sequence -> target[b,h] = t_h (rows of head h to keep), new_lens
@@ -147,21 +168,32 @@ __global__ __launch_bounds__(SEL_T) void select_joint_kernel(
     int quota;
     radix_select_desc(base, 1, n, r, hist, s_state, v, quota);
     // count kept pairs per head; ties at v are taken in ascending flat index (running tie counter)
-    const int stride = (SEL_T / H) * H;  // multiple of H: a thread always sees the same head
-    int local = 0;
     int ties_before = 0;
-    for (int i0 = 0; i0 < n; i0 += stride) {
-      const int i = i0 + tid;
-      const bool in = tid < stride && i < n;
-      uint32_t k = 0;
-      if (in) k = order_key(base[i]);
-      const bool tie = in && k == v;
+    float nxt[SEL_E];
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) nxt[e] = tid * SEL_E + e < n ? base[tid * SEL_E + e] : 0.f;
+    for (int i0 = 0; i0 < n; i0 += SEL_T * SEL_E) {
+      uint32_t key[SEL_E];
+      bool in[SEL_E];
+      int ntie = 0;
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        in[e] = i0 + tid * SEL_E + e < n;
+        key[e] = order_key(nxt[e]);
+        const int i2 = i0 + SEL_T * SEL_E + tid * SEL_E + e;
+        nxt[e] = i2 < n ? base[i2] : 0.f;
+        ntie += (in[e] && key[e] == v) ? 1 : 0;
+      }
       int tot;
-      const int tr = block_excl_scan_flag(tie, s_wsum, tot);
-      if (in && (k > v || (tie && ties_before + tr < quota))) ++local;
+      int tr = ties_before + block_excl_scan_cnt(ntie, s_wsum, tot);
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        const bool tie = in[e] && key[e] == v;
+        if (in[e] && (key[e] > v || (tie && tr < quota))) atomicAdd(&s_cnt[(i0 + tid * SEL_E + e) % H], 1);
+        tr += tie ? 1 : 0;
+      }
       ties_before += tot;
     }
-    if (local) atomicAdd(&s_cnt[tid % H], local);
     __syncthreads();
   }
   if (tid < H) {
@@ -203,17 +235,36 @@ __global__ __launch_bounds__(SEL_T) void select_head_kernel(const float* __restr
   int quota;
   radix_select_desc(base, H, Lb, t, hist, s_state, v, quota);
   int ties_before = 0, kept_before = 0;
-  for (int i0 = 0; i0 < Lb; i0 += SEL_T) {
-    const int i = i0 + tid;
-    const bool in = i < Lb;
-    uint32_t k = 0;
-    if (in) k = order_key(base[(size_t)i * H]);
-    const bool tie = in && k == v;
+  float nxt[SEL_E];
+#pragma unroll
+  for (int e = 0; e < SEL_E; ++e) nxt[e] = tid * SEL_E + e < Lb ? base[(size_t)(tid * SEL_E + e) * H] : 0.f;
+  for (int i0 = 0; i0 < Lb; i0 += SEL_T * SEL_E) {
+    uint32_t key[SEL_E];
+    bool in[SEL_E];
+    int ntie = 0;
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) {
+      in[e] = i0 + tid * SEL_E + e < Lb;
+      key[e] = order_key(nxt[e]);
+      const int i2 = i0 + SEL_T * SEL_E + tid * SEL_E + e;
+      nxt[e] = i2 < Lb ? base[(size_t)i2 * H] : 0.f;
+      ntie += (in[e] && key[e] == v) ? 1 : 0;
+    }
     int tot_t, tot_k;
-    const int tr = block_excl_scan_flag(tie, s_wsum, tot_t);
-    const bool keep = in && (k > v || (tie && ties_before + tr < quota));
-    const int slot = block_excl_scan_flag(keep, s_wsum, tot_k);
-    if (keep) list[kept_before + slot] = i;
+    int tr = ties_before + block_excl_scan_cnt(ntie, s_wsum, tot_t);
+    bool keep[SEL_E];
+    int nkeep = 0;
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) {
+      const bool tie = in[e] && key[e] == v;
+      keep[e] = in[e] && (key[e] > v || (tie && tr < quota));
+      tr += tie ? 1 : 0;
+      nkeep += keep[e] ? 1 : 0;
+    }
+    int slot = kept_before + block_excl_scan_cnt(nkeep, s_wsum, tot_k);
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e)
+      if (keep[e]) list[slot++] = i0 + tid * SEL_E + e;
     ties_before += tot_t;
     kept_before += tot_k;
   }

@@ -94,6 +94,60 @@ def bench_prefill(args):
         print(f"prefill B={B} L={L}: {us / 1e3:9.3f} ms  {flops / us / 1e6:8.1f} TFLOP/s (causal flops)", flush=True)
 
 
+def bench_scoring(args):
+    """Stand-alone cost of every store-stream / scoring kernel at the C3 layer shape (nothing else running)."""
+    from compactor_vllm_amd.compression.common import extract_and_store_top_kv, select_retained
+    from compactor_vllm_amd.compression.compactor import approximate_leverage_scores, non_causal_attn_scores
+    from compactor_vllm_amd.compression.snapkv import query_aware_key_scores
+    from compactor_vllm_amd.kv_cache.store_kv_cache import prefill_store_all_kv
+
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16
+    B, HQ, HKV, D, PS, L = args.B, 32, 8, 128, 128, args.L
+    N = B * L
+    q = (torch.randn(N, HQ, D, device=dev) * 0.3).to(dtype)
+    k = (torch.randn(N, HKV, D, device=dev) * 0.3).to(dtype)
+    v = torch.randn(N, HKV, D, device=dev).to(dtype)
+    PHI = (torch.randn(D, 48, device=dev) / 48 ** 0.5).to(dtype)
+    cu = (torch.arange(0, B + 1, device=dev) * L).to(torch.int32)
+    lens = [L] * B
+    P = -(-L // PS)
+    n_pages = (B + 1) * HKV * P
+    pt = torch.randperm(n_pages, device=dev).view(B + 1, HKV, P).to(torch.int32)
+    bm = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
+    kc = torch.zeros(n_pages * PS, D, dtype=dtype, device=dev)
+    vc = torch.zeros_like(kc)
+    pre = approximate_leverage_scores(k, lens, PHI, normalize=True, chunk_size=512)
+    sc = non_causal_attn_scores(q, k, v, cu, L, chunk_size=128, sm_scale=1.0, normalize=True, accum_scores=pre,
+                                context_lens=lens, protected_first_tokens=[16] * B, protected_last_tokens=[64] * B,
+                                accum_blending=0.5)
+    retain = torch.tensor([max(int(round(0.5 * (L - 80) * HKV)), 1)] * B, dtype=torch.int32, device=dev)
+    zero = torch.zeros(B, HKV, dtype=torch.int32, device=dev)
+
+    def store_top():
+        l = zero.clone()
+        extract_and_store_top_kv(sc, cu, L, L * HKV, HKV, k, v, retain, pt, bm, l, kc, vc, PS)
+
+    def store_all():
+        l = zero.clone()
+        prefill_store_all_kv(new_keys=k, new_values=v, cu_seqlens_k=cu, max_seqlen_k=L, k_cache=kc, v_cache=vc,
+                             page_table=pt, bh_lens=l, batch_mapping=bm, PAGE_SIZE=PS)
+
+    items = [
+        ("leverage (sketch+solve+zscore)", lambda: approximate_leverage_scores(k, lens, PHI, normalize=True, chunk_size=512)),
+        ("chunk mass + zscore + blend + protect", lambda: non_causal_attn_scores(
+            q, k, v, cu, L, chunk_size=128, sm_scale=1.0, normalize=True, accum_scores=pre, context_lens=lens,
+            protected_first_tokens=[16] * B, protected_last_tokens=[64] * B, accum_blending=0.5)),
+        ("snapkv scores", lambda: query_aware_key_scores(q, k, cu, cu, w=32, max_seqlen_k=L)),
+        ("select (joint + per-head)", lambda: select_retained(sc, cu, L, retain, bm, zero, PS, True)),
+        ("select + compaction", store_top),
+        ("store_all", store_all),
+    ]
+    for name, fn in items:
+        us = time_fn(fn, iters=10, warmup=3)
+        print(f"scoring B={B} L={L}: {name:42s} {us:9.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what")
@@ -102,4 +156,4 @@ if __name__ == "__main__":
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1)
     a = ap.parse_args()
-    {"decode": bench_decode, "prefill": bench_prefill}[a.what](a)
+    {"decode": bench_decode, "prefill": bench_prefill, "scoring": bench_scoring}[a.what](a)
