@@ -58,6 +58,10 @@ def shell():
         L.shell_silu_mul.argtypes = [P, P, ctypes.c_long, I, P]
         L.shell_gemv.argtypes = [P, P, P, I, I, I, P]
         L.shell_gemv.restype = I
+        L.shell_gemv_norm.argtypes = [P, P, P, P, P, P, I, I, F, P]
+        L.shell_gemv_norm.restype = I
+        L.shell_gemv_silu.argtypes = [P, P, P, I, I, P]
+        L.shell_gemv_silu.restype = I
         for f in (L.shell_add_rmsnorm, L.shell_rope, L.shell_silu_mul):
             f.restype = None
         _shell = L
@@ -155,6 +159,8 @@ class ModelShell:
         H, D, I = cfg.hidden, cfg.head_dim, cfg.intermediate
         ctx = get_context()
         h = self.embed.index_select(0, tokens)
+        if N == 1 and USE_SHELL_GEMV and not ctx.is_prefill:
+            return self._forward_one_token(h, positions)
         x = torch.empty_like(h)
         delta = None
         for li, L in enumerate(self.layers):
@@ -200,6 +206,40 @@ class ModelShell:
                             cfg.rms_eps, _st())
         logits = linear(xf, self.lm_head)
         return logits.argmax(dim=-1)  # temperature 0
+
+    def _forward_one_token(self, h: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        """Decode step for one sequence: 8 launches per layer (norm+qkv GEMV, RoPE, attention stream, split merge,
+        o GEMV, norm+gate_up GEMV, silu+down GEMV) - the RMSNorm / residual add / SiLU*mul producers are folded
+        into the x-load of the GEMV that consumes them."""
+        cfg, S = self.cfg, shell()
+        H, D, I = cfg.hidden, cfg.head_dim, cfg.intermediate
+        dt, dev = h.dtype, h.device
+        ha, hb = h, torch.empty_like(h)  # residual stream ping-pong (the fused kernels must not alias in/out)
+        delta = None
+        for li, L in enumerate(self.layers):
+            qkv = torch.empty((1, self.qsz + 2 * self.kvsz), dtype=dt, device=dev)
+            S.shell_gemv_norm(L["wqkv"].data_ptr(), ha.data_ptr(), hb.data_ptr(),
+                              None if delta is None else delta.data_ptr(), L["n1"].data_ptr(), qkv.data_ptr(),
+                              self.qsz + 2 * self.kvsz, H, cfg.rms_eps, _st())
+            ha, hb = hb, ha
+            v = qkv[:, self.qsz + self.kvsz :].view(1, cfg.kv_heads, D)
+            qk = torch.empty((1, cfg.heads + cfg.kv_heads, D), dtype=dt, device=dev)
+            S.shell_rope(qkv.data_ptr(), qkv.stride(0), qk.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
+                         None if L["qn"] is None else L["qn"].data_ptr(),
+                         None if L["kn"] is None else L["kn"].data_ptr(), 1, cfg.heads + cfg.kv_heads, cfg.heads,
+                         cfg.rms_eps, _st())
+            o = self.attn[li](qk[:, : cfg.heads], qk[:, cfg.heads :], v, None)
+            delta = linear(o.view(1, self.qsz), L["wo"])
+            gu = torch.empty((1, 2 * I), dtype=dt, device=dev)
+            S.shell_gemv_norm(L["wgu"].data_ptr(), ha.data_ptr(), hb.data_ptr(), delta.data_ptr(), L["n2"].data_ptr(),
+                              gu.data_ptr(), 2 * I, H, cfg.rms_eps, _st())
+            ha, hb = hb, ha
+            delta = torch.empty((1, H), dtype=dt, device=dev)
+            S.shell_gemv_silu(L["wd"].data_ptr(), gu.data_ptr(), delta.data_ptr(), H, I, _st())
+        logits = torch.empty((1, cfg.vocab), dtype=dt, device=dev)
+        S.shell_gemv_norm(self.lm_head.data_ptr(), ha.data_ptr(), hb.data_ptr(), delta.data_ptr(),
+                          self.final_norm.data_ptr(), logits.data_ptr(), cfg.vocab, H, cfg.rms_eps, _st())
+        return logits.argmax(dim=-1)
 
     # ---- generate: prefill (+ compression overlapped on the store stream) then HIP-graph decode ----------------
     def generate(self, prompts: list, max_new_tokens: int, method: CompressionMethod, ratio: float,

@@ -71,7 +71,7 @@ __device__ void radix_select_desc(const float* __restrict__ base, int stride, in
           const unsigned long long am = __ballot(act);
           if (am == 0ull) break;
           const int leader = __ffsll((long long)am) - 1;
-          const uint32_t ld = __shfl((int)digit, leader, 64);
+          const uint32_t ld = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);  // leader is wave-uniform
           const unsigned long long mm = __ballot(act && digit == ld);
           if ((tid & 63) == leader) atomicAdd(&hist[ld], (uint32_t)__popcll(mm));
           if (digit == ld) act = false;

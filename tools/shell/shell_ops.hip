@@ -157,6 +157,120 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint16_t* __restrict__ 
   }
 }
 
+// Decode-step (one token) GEMV with the producer fused into the x load:
+//   MODE 1: x = rmsnorm(h + delta) * nw   (block 0 also writes h_out = h + delta, the residual stream; h_out must
+//           not alias h: other blocks are still reading h)
+//   MODE 2: x = silu(gu[0:K]) * gu[K:2K]
+// Every block recomputes the K-element prologue (K <= 14336: a few hundred cycles) instead of a separate launch.
+template <int MODE, int RPW>
+__global__ __launch_bounds__(256) void gemv_fused_kernel(const uint16_t* __restrict__ W, const uint16_t* __restrict__ h,
+                                                         uint16_t* __restrict__ h_out,
+                                                         const uint16_t* __restrict__ delta,
+                                                         const uint16_t* __restrict__ nw,
+                                                         const uint16_t* __restrict__ gu, uint16_t* __restrict__ y,
+                                                         int N, int K, float eps) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_x[];  // [K]
+  __shared__ float s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (MODE == 1) {
+    float ss = 0.f;
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      uint4 hv = *reinterpret_cast<const uint4*>(h + i);
+      uint16_t* hp = reinterpret_cast<uint16_t*>(&hv);
+      if (delta) {
+        uint4 dv = *reinterpret_cast<const uint4*>(delta + i);
+        const uint16_t* dp = reinterpret_cast<const uint16_t*>(&dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hp[j] = f2bf(bf2f(hp[j]) + bf2f(dp[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf2f(hp[j]);
+        ss += f * f;
+      }
+      *reinterpret_cast<uint4*>(s_x + i) = hv;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) s_part[wave] = ss;
+    __syncthreads();
+    const float inv = rsqrtf((s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)K + eps);
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      uint4 hv = *reinterpret_cast<const uint4*>(s_x + i);
+      uint4 wv = *reinterpret_cast<const uint4*>(nw + i);
+      if (blockIdx.x == 0) *reinterpret_cast<uint4*>(h_out + i) = hv;  // residual stream, written once
+      uint16_t* hp = reinterpret_cast<uint16_t*>(&hv);
+      const uint16_t* wp = reinterpret_cast<const uint16_t*>(&wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hp[j] = f2bf(bf2f(hp[j]) * inv * bf2f(wp[j]));
+      *reinterpret_cast<uint4*>(s_x + i) = hv;
+    }
+  } else {
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      uint4 gv = *reinterpret_cast<const uint4*>(gu + i);
+      uint4 uv = *reinterpret_cast<const uint4*>(gu + K + i);
+      uint16_t* gp = reinterpret_cast<uint16_t*>(&gv);
+      const uint16_t* up = reinterpret_cast<const uint16_t*>(&uv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = bf2f(gp[j]);
+        gp[j] = f2bf(g / (1.f + __expf(-g)) * bf2f(up[j]));
+      }
+      *reinterpret_cast<uint4*>(s_x + i) = gv;
+    }
+  }
+  __syncthreads();
+  const int nchunk = K / 8;
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < N; row0 += gridDim.x * 4 * RPW) {
+    float acc[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+      u32x4_t w[RPW];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, N - 1);
+        w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W + (size_t)row * K + c * 8));
+      }
+      const uint4 xv = *reinterpret_cast<const uint4*>(s_x + c * 8);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        float a = acc[r];
+        a = dot2bf(w[r].x, xv.x, a);
+        a = dot2bf(w[r].y, xv.y, a);
+        a = dot2bf(w[r].z, xv.z, a);
+        a = dot2bf(w[r].w, xv.w, a);
+        acc[r] = a;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const float t = wave_sum(acc[r]);
+      if (lane == 0 && row0 + r < N) y[row0 + r] = f2bf(t);
+    }
+  }
+}
+
+extern "C" int shell_gemv_norm(const void* W, const void* h, void* h_out, const void* delta, const void* nw, void* y,
+                               int N, int K, float eps, void* stream) {
+  if (h == h_out) return -1;
+  if (K % 8 || (size_t)K * 2 > 64 * 1024) return -1;
+  int blocks = (N + 15) / 16;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((gemv_fused_kernel<1, 4>), dim3(blocks), dim3(256), (size_t)K * 2, (hipStream_t)stream,
+                     (const uint16_t*)W, (const uint16_t*)h, (uint16_t*)h_out, (const uint16_t*)delta,
+                     (const uint16_t*)nw, nullptr, (uint16_t*)y, N, K, eps);
+  return 0;
+}
+extern "C" int shell_gemv_silu(const void* W, const void* gu, void* y, int N, int K, void* stream) {
+  if (K % 8 || (size_t)K * 2 > 64 * 1024) return -1;
+  int blocks = (N + 15) / 16;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((gemv_fused_kernel<2, 4>), dim3(blocks), dim3(256), (size_t)K * 2, (hipStream_t)stream,
+                     (const uint16_t*)W, nullptr, nullptr, nullptr, nullptr, (const uint16_t*)gu, (uint16_t*)y, N, K,
+                     0.f);
+  return 0;
+}
+
 extern "C" int shell_gemv(const void* W, const void* x, void* y, int B, int N, int K, void* stream) {
   if (K % 8 || B < 1 || B > 4) return -1;
   const size_t smem = (size_t)B * K * 2;
