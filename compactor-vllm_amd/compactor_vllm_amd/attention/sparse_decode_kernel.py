@@ -128,7 +128,9 @@ def fused_decode_step(
     _lib.require_cuda(q, key, value, k_cache, v_cache, bh_seq_lens_layer, page_table, batch_mapping)
     B, HQ, D = q.shape
     assert key.shape == (B, HKV, D) and value.shape == (B, HKV, D)
-    assert q.is_contiguous() and key.stride(-1) == 1 and value.stride(-1) == 1
+    if not q.is_contiguous():
+        q = q.contiguous()  # e.g. a view of a fused [B, HQ+HKV, D] RoPE output
+    assert key.stride(-1) == 1 and value.stride(-1) == 1
     assert PAGE_SIZE % 32 == 0 and HQ % HKV == 0
     assert bh_seq_lens_layer.is_contiguous() and bh_seq_lens_layer.dtype == torch.int32
     assert batch_mapping.dtype == torch.int32 and page_table.is_contiguous() and page_table.dtype == torch.int32

@@ -31,88 +31,6 @@ __device__ __forceinline__ uint32_t order_key(float x) {
 constexpr int SEL_E = 4;  // elements per thread per iteration: 4 independent loads in flight (the loops are
                           // L2-latency bound with one), thread t owns the CONSECUTIVE indices base + 4t .. +3
 
-// Exact selection of the r-th largest (1-based, 1 <= r <= n) ordered key among n strided floats.
-// Returns the key value v and `quota` = how many elements equal to v belong to the top r
-// (count(key > v) = r - quota).  All SEL_T threads must call; hist is LDS [256], s_state LDS [2].
-__device__ void radix_select_desc(const float* __restrict__ base, int stride, int n, int r, uint32_t* hist,
-                                  uint32_t* s_state, uint32_t& v_out, int& quota_out) {
-  const int tid = threadIdx.x;
-  uint32_t prefix = 0;
-  int remaining = r;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    float nxt[SEL_E];  // software prefetch: the next iteration's loads are in flight while this one is binned
-#pragma unroll
-    for (int e = 0; e < SEL_E; ++e) {
-      const int i = tid * SEL_E + e;
-      nxt[e] = i < n ? base[(size_t)i * stride] : 0.f;
-    }
-    for (int i0 = 0; i0 < n; i0 += SEL_T * SEL_E) {
-      uint32_t key[SEL_E];
-      bool in[SEL_E];
-#pragma unroll
-      for (int e = 0; e < SEL_E; ++e) {
-        in[e] = i0 + tid * SEL_E + e < n;
-        key[e] = order_key(nxt[e]);
-        const int i2 = i0 + SEL_T * SEL_E + tid * SEL_E + e;
-        nxt[e] = i2 < n ? base[(size_t)i2 * stride] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < SEL_E; ++e) {
-        bool act = in[e] && (pass == 0 || (key[e] >> (shift + 8)) == prefix);
-        const uint32_t digit = (key[e] >> shift) & 0xffu;
-        // wave-aggregated histogram: each leader round retires one distinct digit of the wave with ONE atomic
-        // (z-scored data puts a wave's 64 keys into a handful of top-byte bins: same-address LDS atomics would
-        // serialise ~30-way); anything still active after 12 rounds falls back to per-lane atomics
-#pragma unroll 1
-        for (int round = 0; round < 12; ++round) {
-          const unsigned long long am = __ballot(act);
-          if (am == 0ull) break;
-          const int leader = __ffsll((long long)am) - 1;
-          const uint32_t ld = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);  // leader is wave-uniform
-          const unsigned long long mm = __ballot(act && digit == ld);
-          if ((tid & 63) == leader) atomicAdd(&hist[ld], (uint32_t)__popcll(mm));
-          if (digit == ld) act = false;
-        }
-        if (act) atomicAdd(&hist[digit], 1u);
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {  // one wave walks the 256 bins from the top: 4 bins per lane, lane 0 owns the largest
-      const int lane = tid;
-      const int b0 = 255 - 4 * lane;
-      const uint32_t c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
-      const uint32_t mine = c0 + c1 + c2 + c3;
-      uint32_t incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      const uint32_t excl = incl - mine;  // elements in strictly larger bins than this lane's four
-      const uint32_t rem = (uint32_t)remaining;
-      if (excl < rem && rem <= incl) {
-        uint32_t acc = excl;
-        int d = b0;
-        if (acc + c0 >= rem) { d = b0; }
-        else { acc += c0; if (acc + c1 >= rem) { d = b0 - 1; }
-        else { acc += c1; if (acc + c2 >= rem) { d = b0 - 2; }
-        else { acc += c2; d = b0 - 3; } } }
-        s_state[0] = (uint32_t)d;
-        s_state[1] = rem - acc;  // remaining rank inside bin d
-      }
-    }
-    __syncthreads();
-    prefix = (prefix << 8) | s_state[0];
-    remaining = (int)s_state[1];
-    __syncthreads();
-  }
-  v_out = prefix;
-  quota_out = remaining;
-}
-
 // block-wide exclusive scan of a small per-thread count over SEL_T threads (thread order = index order)
 __device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,12 +54,86 @@ __device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& to
   return woff + incl - cnt;
 }
 
+// Exact selection of the r-th largest (1-based, 1 <= r <= n) ordered key among n strided floats: three radix
+// passes over 12 + 12 + 8 key bits with a 4096-bin LDS histogram.  12-bit digits spread z-scored data over
+// hundreds of bins, so plain LDS atomics see few same-address conflicts (an 8-bit first digit put a wave's 64
+// keys into a handful of bins and serialised ~30-way; leader-aggregation rounds cost more than they saved).
+// Returns the key value v and `quota` = how many elements equal to v belong to the top r
+// (count(key > v) = r - quota).  All SEL_T threads must call; hist is LDS [4096], s_state LDS [2], s_wsum [SEL_W].
+constexpr int SEL_BINS = 4096;
+__device__ void radix_select_desc(const float* __restrict__ base, int stride, int n, int r, uint32_t* hist,
+                                  uint32_t* s_state, int* s_wsum, uint32_t& v_out, int& quota_out) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0;  // the key bits fixed so far (high bits)
+  int remaining = r;
+  int fixed_bits = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int bits = pass < 2 ? 12 : 8;
+    const int shift = 32 - fixed_bits - bits;
+    const uint32_t dmask = (1u << bits) - 1u;
+    for (int i = tid; i < SEL_BINS; i += SEL_T) hist[i] = 0;
+    __syncthreads();
+    float nxt[SEL_E];  // software prefetch: the next iteration's loads are in flight while this one is binned
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) {
+      const int i = tid * SEL_E + e;
+      nxt[e] = i < n ? base[(size_t)i * stride] : 0.f;
+    }
+    for (int i0 = 0; i0 < n; i0 += SEL_T * SEL_E) {
+      uint32_t key[SEL_E];
+      bool in[SEL_E];
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        in[e] = i0 + tid * SEL_E + e < n;
+        key[e] = order_key(nxt[e]);
+        const int i2 = i0 + SEL_T * SEL_E + tid * SEL_E + e;
+        nxt[e] = i2 < n ? base[(size_t)i2 * stride] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        const bool act = in[e] && (fixed_bits == 0 || (key[e] >> (32 - fixed_bits)) == prefix);
+        if (act) atomicAdd(&hist[(key[e] >> shift) & dmask], 1u);
+      }
+    }
+    __syncthreads();
+    // walk the bins from the top: thread t owns bins top-4t .. top-4t-3 (top = 2^bits - 1); block scan of the sums
+    {
+      const int nb = 1 << bits;
+      const int b0 = nb - 1 - 4 * tid;
+      uint32_t c[4] = {0, 0, 0, 0};
+      if (b0 >= 3) {
+        c[0] = hist[b0]; c[1] = hist[b0 - 1]; c[2] = hist[b0 - 2]; c[3] = hist[b0 - 3];
+      }
+      const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
+      int tot;
+      const int excl = block_excl_scan_cnt(mine, s_wsum, tot);  // elements in strictly larger bins
+      if (excl < remaining && remaining <= excl + mine) {
+        int acc = excl, d = b0;
+        if (acc + (int)c[0] >= remaining) { d = b0; }
+        else { acc += c[0]; if (acc + (int)c[1] >= remaining) { d = b0 - 1; }
+        else { acc += c[1]; if (acc + (int)c[2] >= remaining) { d = b0 - 2; }
+        else { acc += c[2]; d = b0 - 3; } } }
+        s_state[0] = (uint32_t)d;
+        s_state[1] = (uint32_t)(remaining - acc);  // remaining rank inside bin d
+      }
+    }
+    __syncthreads();
+    prefix = (prefix << bits) | s_state[0];
+    remaining = (int)s_state[1];
+    fixed_bits += bits;
+    __syncthreads();
+  }
+  v_out = prefix;
+  quota_out = remaining;
+}
+
 // kernel 1: one workgroup per sequence -> target[b,h] = t_h (rows of head h to keep), new_lens
 __global__ __launch_bounds__(SEL_T) void select_joint_kernel(
     const float* __restrict__ scores, const int* __restrict__ cu, const int* __restrict__ retain,
     const int* __restrict__ bh_lens0, const int* __restrict__ bmap, int* __restrict__ target,
     int* __restrict__ new_lens, int H, int PS, int pad, int reserved) {
-  __shared__ uint32_t hist[256];
+  __shared__ uint32_t hist[SEL_BINS];
   __shared__ uint32_t s_state[2];
   __shared__ int s_wsum[SEL_W];
   __shared__ int s_cnt[SEL_MAXH];
@@ -166,9 +158,16 @@ __global__ __launch_bounds__(SEL_T) void select_joint_kernel(
   if (r > 0) {
     uint32_t v;
     int quota;
-    radix_select_desc(base, 1, n, r, hist, s_state, v, quota);
+    radix_select_desc(base, 1, n, r, hist, s_state, s_wsum, v, quota);
     // count kept pairs per head; ties at v are taken in ascending flat index (running tie counter)
     int ties_before = 0;
+    // (SEL_T*SEL_E) % H == 0 (H a power of two): element e of thread t always belongs to head (4t+e) % H, so
+    // the per-head counts accumulate in registers and hit LDS once at the end (per-element LDS atomics on H
+    // addresses serialised ~32-way and dominated the kernel)
+    const bool fixed_head = ((SEL_T * SEL_E) % H) == 0;
+    int local[SEL_E];
+#pragma unroll
+    for (int e = 0; e < SEL_E; ++e) local[e] = 0;
     float nxt[SEL_E];
 #pragma unroll
     for (int e = 0; e < SEL_E; ++e) nxt[e] = tid * SEL_E + e < n ? base[tid * SEL_E + e] : 0.f;
@@ -189,10 +188,18 @@ __global__ __launch_bounds__(SEL_T) void select_joint_kernel(
 #pragma unroll
       for (int e = 0; e < SEL_E; ++e) {
         const bool tie = in[e] && key[e] == v;
-        if (in[e] && (key[e] > v || (tie && tr < quota))) atomicAdd(&s_cnt[(i0 + tid * SEL_E + e) % H], 1);
+        if (in[e] && (key[e] > v || (tie && tr < quota))) {
+          if (fixed_head) ++local[e];
+          else atomicAdd(&s_cnt[(i0 + tid * SEL_E + e) % H], 1);
+        }
         tr += tie ? 1 : 0;
       }
       ties_before += tot;
+    }
+    if (fixed_head) {
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e)
+        if (local[e]) atomicAdd(&s_cnt[(tid * SEL_E + e) % H], local[e]);
     }
     __syncthreads();
   }
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(SEL_T) void select_head_kernel(const float* __restr
                                                             const int* __restrict__ cu,
                                                             const int* __restrict__ target,
                                                             int* __restrict__ kept_idx, int H, int max_seqlen) {
-  __shared__ uint32_t hist[256];
+  __shared__ uint32_t hist[SEL_BINS];
   __shared__ uint32_t s_state[2];
   __shared__ int s_wsum[SEL_W];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(SEL_T) void select_head_kernel(const float* __restr
   }
   uint32_t v;
   int quota;
-  radix_select_desc(base, H, Lb, t, hist, s_state, v, quota);
+  radix_select_desc(base, H, Lb, t, hist, s_state, s_wsum, v, quota);
   int ties_before = 0, kept_before = 0;
   float nxt[SEL_E];
 #pragma unroll

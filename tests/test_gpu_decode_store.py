@@ -203,6 +203,8 @@ def test_select_compact_golden(dev, name):
     (2, 4, [700, 300], 0.5, True),      # heavy ties: quantised scores + inf blocks
     (2, 2, [5, 128], 1.0, False),       # first+last >= L  (quirk Q2: retain = 1)
     (4, 1, [64, 65, 127, 129], 0.7, True),
+    (2, 3, [500, 129], 0.4, True),      # H not a power of two: per-element counting fallback
+    (1, 6, [1000], 0.3, False),
 ])
 def test_select_oracle_random(dev, B, H, lens, ratio, ties):
     """Against the CPU oracle with the canonical tie rule (score desc, flat index asc), incl. tie-heavy
