@@ -49,6 +49,9 @@ __device__ __forceinline__ uint32_t v_off(int row, int ch) {
   return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+// LDS-visibility barrier without hipcc's vmcnt(0) drain: only LDS traffic has to be complete at the rendezvous.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename T, int D, int G>
 __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, int64_t sq_n,
@@ -159,14 +162,15 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   const int tq = li >> 2, tp = li & 3;
 
   // ---- main loop: one 64-key tile per iteration ------------------------------------------------------------------
-  // Global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after
-  // them; one barrier per tile.  (A half-tile stagger of waves 4-7 against waves 0-3 - so that SIMD partners sit
-  // in opposite MFMA / VALU phases - was built with 3 LDS buffers and two barriers per tile and measured SLOWER
-  // (760 vs 842 TFLOP/s at 32K): the second barrier costs more than the overlap returns.)
+  // Global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after them;
+  // one barrier per tile.  Measured alternatives (32K tokens, bf16): a half-tile stagger of waves 4-7 against
+  // waves 0-3 (same code, 3 LDS buffers, two raw barriers per tile) so that SIMD partners sit in opposite
+  // MFMA / VALU phases: 786 vs 840 TFLOP/s - the second rendezvous per tile costs more than the overlap returns;
+  // a two-segment software pipeline with per-group code paths: spills, 312 TFLOP/s.
   kr0 = kr1 = vr0 = vr1 = make_uint4(0, 0, 0, 0);
   gload(0);
   lstore(0);
-  __syncthreads();
+  lds_barrier();
 
   for (int t = 0; t < ntiles; ++t) {
     const int buf = (dbg & 1) ? 0 : (t & 1);
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
       }
     }
     if (t + 1 < ntiles && !(dbg & 1)) lstore(buf ^ 1);
-    if (!(dbg & 16)) __syncthreads();
+    if (!(dbg & 16)) lds_barrier();
   }
 
   // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ------------------------
