@@ -63,9 +63,19 @@ __device__ __forceinline__ uint16_t to16<BF16>(float x) {
   __bf16 h = (__bf16)x;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
   return __builtin_bit_cast(uint16_t, h);
 }
+// two fp32 -> one packed 16-bit pair, RNE (built as a vector so that hipcc selects ONE v_cvt_pk_{bf16,f16}_f32
+// instead of two conversions and an OR)
 template <typename T>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)to16<T>(lo) | ((uint32_t)to16<T>(hi) << 16);
+__device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <>
+__device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
+  half2_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+template <>
+__device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
+  bf162_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 template <typename T>
 __device__ __forceinline__ float from16(uint16_t b);

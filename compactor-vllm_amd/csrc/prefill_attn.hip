@@ -39,14 +39,35 @@ __device__ __forceinline__ f32x16 mfma32<BF16>(s16x8 a, s16x8 b, f32x16 c) {
 constexpr int PF_ROWS = 256;   // query rows per workgroup
 constexpr int PF_KT = 64;      // keys per tile
 constexpr int PF_THREADS = 512;
-constexpr int PF_TILE_BYTES = PF_KT * 256;        // one K or V tile image (256-byte rows)
+constexpr int PF_KSTR = 272;                      // K image row stride: 256 + 16 B pad -> conflict-free ds_read_b128
+constexpr int PF_VSTR = 320;                      // V image row stride: 256 + 64 B pad -> conflict-free ds_read_b64_tr_b16
+constexpr int PF_KTILE = PF_KT * PF_KSTR;         // 17,408 B
+constexpr int PF_VTILE = PF_KT * PF_VSTR;         // 20,480 B
 constexpr int PF_OSTRIDE = 272;                   // padded row stride of the O staging image
-constexpr int PF_SMEM = (4 * PF_TILE_BYTES > 8 * 32 * PF_OSTRIDE) ? 4 * PF_TILE_BYTES : 8 * 32 * PF_OSTRIDE;  // 2 x (K + V)
+constexpr int PF_SMEM = 2 * PF_KTILE + 3 * PF_VTILE;  // 2 K tiles + 3 V tiles = 96,256 B
+static_assert(PF_SMEM >= 8 * 32 * PF_OSTRIDE, "O staging image must fit");
 
-// K image: row-wise ds_read_b128 (T2 swizzle);  V image: transposed ds_read_b64_tr_b16 (guide T10 layout (b))
-__device__ __forceinline__ uint32_t k_off(int row, int ch) { return row * 256 + 16 * (ch ^ (row & 15)); }
-__device__ __forceinline__ uint32_t v_off(int row, int ch) {
-  return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+// Padded (not XOR-swizzled) images: every fragment address of the main loop is ONE lane-constant VGPR plus an
+// immediate offset, so the loop spends no VALU on LDS addressing (VALU issue, shared by the two waves of a SIMD,
+// is what bounds this kernel: MI355X guide, 'vector-instruction ISSUE cost').
+//   K: lanes r = 0..15 of a ds_read_b128 group read rows r at the same column -> bank (68 r) % 64 = 4 r: distinct.
+//   V: a 32-lane half of ds_read_b64_tr_b16 reads 4 rows x 64 contiguous bytes -> row shift 80 % 64 = 16 banks.
+
+// max(a, b, c) without the v_max x,x canonicalisation hipcc puts in front of every fmaxf of an MFMA result
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// row max of one query over the wave's 64 keys: 32 in-lane values, then the partner lane (l ^ 32)
+__device__ __forceinline__ float tile_max(const f32x16& a, const f32x16& b) {
+  float m0 = max3(a[0], a[1], a[2]), m1 = max3(b[0], b[1], b[2]);
+#pragma unroll
+  for (int i = 3; i < 15; i += 2) m0 = max3(m0, a[i], a[i + 1]), m1 = max3(m1, b[i], b[i + 1]);
+  const float mx = max3(m0, m1, fmaxf(a[15], b[15]));
+  // partner lane l ^ 32 by v_permlane32_swap (VALU; no LDS round trip as with ds_bpermute)
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+  return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
 }
 
 // LDS-visibility barrier without hipcc's vmcnt(0) drain: only LDS traffic has to be complete at the rendezvous.
@@ -116,34 +137,47 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   // block).  Rows past the end of the tile are CLAMPED to the last valid row instead of being skipped: their
   // logits are masked to -inf (P = 0) and the clamped row is finite data, so 0 * V stays 0 - and the loads stay
   // unconditional (a per-row "load or zero" select makes hipcc branch around every load and serialise them).
+  // Pages of PS % 64 == 0 keep a whole 64-key tile inside one page: the page id is a wave-uniform scalar load issued
+  // one tile ahead and the page walk is incremental (no per-row division, no dependent vector load of the page table
+  // at the top of every iteration).  Other page sizes take the per-row path.
+  const bool ps64 = (PS % PF_KT) == 0;
+  int ld_pi = 0, ld_po = 0;                 // page index / offset in page of the next cached tile to load
+  int ld_pg = (ntc > 0) ? pt[0] : 0;        // its physical page
+  const uint32_t skn = (uint32_t)sk_n, svn = (uint32_t)sv_n;  // row strides < 2^31 elements (checked on the host)
   auto gload = [&](int t) {
-    if (stage_active) {
-      if (t < ntc) {
+    if (t < ntc) {
+      size_t o0, o1;
+      if (ps64) {
+        const int last = Lc - 1 - t * PF_KT;  // >= 0
+        const size_t rowbase = (size_t)ld_pg * PS + ld_po;
+        o0 = (rowbase + min(srow, last)) * D + sch * 8;  // int64 row offset (reference :371)
+        o1 = (rowbase + min(srow + 32, last)) * D + sch * 8;
+        ld_po += PF_KT;
+        if (ld_po >= PS) {
+          ld_po = 0;
+          ld_pi += 1;
+          ld_pg = pt[min(ld_pi, NLP - 1)];
+        }
+      } else {
         const int p0 = min(t * PF_KT + srow, Lc - 1), p1 = min(t * PF_KT + srow + 32, Lc - 1);
-        const size_t o0 = ((size_t)pt[p0 / PS] * PS + p0 % PS) * D + sch * 8;  // int64 row offset (reference :371)
-        const size_t o1 = ((size_t)pt[p1 / PS] * PS + p1 % PS) * D + sch * 8;
+        o0 = ((size_t)pt[p0 / PS] * PS + p0 % PS) * D + sch * 8;
+        o1 = ((size_t)pt[p1 / PS] * PS + p1 % PS) * D + sch * 8;
+      }
+      if (stage_active) {
         kr0 = *reinterpret_cast<const uint4*>(kc + o0);
         kr1 = *reinterpret_cast<const uint4*>(kc + o1);
         vr0 = *reinterpret_cast<const uint4*>(vc + o0);
         vr1 = *reinterpret_cast<const uint4*>(vc + o1);
-      } else {
-        const int p0 = min((t - ntc) * PF_KT + srow, la_vis - 1), p1 = min((t - ntc) * PF_KT + srow + 32, la_vis - 1);
-        const size_t n0 = (size_t)(s0 + p0), n1 = (size_t)(s0 + p1);
-        kr0 = *reinterpret_cast<const uint4*>(k + n0 * sk_n + (size_t)g * sk_h + sch * 8);
-        kr1 = *reinterpret_cast<const uint4*>(k + n1 * sk_n + (size_t)g * sk_h + sch * 8);
-        vr0 = *reinterpret_cast<const uint4*>(v + n0 * sv_n + (size_t)g * sv_h + sch * 8);
-        vr1 = *reinterpret_cast<const uint4*>(v + n1 * sv_n + (size_t)g * sv_h + sch * 8);
       }
-    }
-  };
-  auto lstore = [&](int buf) {
-    if (stage_active) {
-      char* kb = smem + buf * 2 * PF_TILE_BYTES;
-      char* vb = kb + PF_TILE_BYTES;
-      *reinterpret_cast<uint4*>(kb + k_off(srow, sch)) = kr0;
-      *reinterpret_cast<uint4*>(kb + k_off(srow + 32, sch)) = kr1;
-      *reinterpret_cast<uint4*>(vb + v_off(srow, sch)) = vr0;
-      *reinterpret_cast<uint4*>(vb + v_off(srow + 32, sch)) = vr1;
+    } else if (stage_active) {
+      const uint32_t n0 = (uint32_t)(s0 + min((t - ntc) * PF_KT + srow, la_vis - 1));
+      const uint32_t n1 = (uint32_t)(s0 + min((t - ntc) * PF_KT + srow + 32, la_vis - 1));
+      const uint16_t* kg = k + (size_t)g * sk_h + sch * 8;
+      const uint16_t* vg = v + (size_t)g * sv_h + sch * 8;
+      kr0 = *reinterpret_cast<const uint4*>(kg + (uint64_t)n0 * skn);
+      kr1 = *reinterpret_cast<const uint4*>(kg + (uint64_t)n1 * skn);
+      vr0 = *reinterpret_cast<const uint4*>(vg + (uint64_t)n0 * svn);
+      vr1 = *reinterpret_cast<const uint4*>(vg + (uint64_t)n1 * svn);
     }
   };
 
@@ -161,56 +195,84 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   const int li = lane & 15;
   const int tq = li >> 2, tp = li & 3;
 
-  // ---- main loop: one 64-key tile per iteration ------------------------------------------------------------------
-  // Global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after them;
-  // one barrier per tile.  Measured alternatives (32K tokens, bf16): a half-tile stagger of waves 4-7 against
-  // waves 0-3 (same code, 3 LDS buffers, two raw barriers per tile) so that SIMD partners sit in opposite
-  // MFMA / VALU phases: 786 vs 840 TFLOP/s - the second rendezvous per tile costs more than the overlap returns;
-  // a two-segment software pipeline with per-group code paths: spills, 312 TFLOP/s.
+  // ---- main loop: one 64-key tile per iteration, software-pipelined by one tile inside every wave -----------------
+  // Iteration t holds the raw logits of tile t in registers (computed one iteration earlier) and issues, in ONE
+  // basic block, the 16 MFMAs of S(t+1) = K(t+1) Q^T next to the exp / pack VALU work of tile t, then the 16 MFMAs
+  // of O += P(t) V(t): the matrix pipe has work while the wave's own softmax runs, without relying on a SIMD
+  // partner being in the opposite phase.  K is double- and V triple-buffered in LDS so that tile t+2 can be written
+  // during iteration t with ONE barrier per tile: K(t+2) replaces K(t) (last read in iteration t-1), V(t+2)
+  // replaces V(t-1).  Global loads of tile t+2 are issued at the top of iteration t and land in LDS at its end.
+  // Measured alternatives (32K tokens, bf16): lock-step phases 840 TFLOP/s; a half-tile stagger of waves 4-7 with
+  // two barriers per tile 786; a two-segment pipeline with per-group code paths: spills, 312.
+  char* const kbase = smem;
+  char* const vbase = smem + 2 * PF_KTILE;
+  const uint32_t kst = srow * PF_KSTR + sch * 16, vst = srow * PF_VSTR + sch * 16;
+  auto lstore = [&](int kbuf, int vbuf) {
+    if (stage_active) {
+      char* kb = kbase + kbuf * PF_KTILE + kst;
+      char* vb = vbase + vbuf * PF_VTILE + vst;
+      *reinterpret_cast<uint4*>(kb) = kr0;
+      *reinterpret_cast<uint4*>(kb + 32 * PF_KSTR) = kr1;
+      *reinterpret_cast<uint4*>(vb) = vr0;
+      *reinterpret_cast<uint4*>(vb + 32 * PF_VSTR) = vr1;
+    }
+  };
+  const uint32_t k_lane = r * PF_KSTR + h * 16;                                           // + 32 s (+ 32 rows)
+  const uint32_t v_lane = (4 * (gi >> 1) + tq) * PF_VSTR + (gi & 1) * 32 + tp * 8;       // + rows, + 64 db
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;  // LDS byte address of the dynamic segment
+  // The tile base is added to the lane constant ONCE and laundered, so that every read below is that VGPR plus an
+  // immediate (left alone, hipcc folds the immediates into the uniform tile base and spends one v_add per read).
+  auto qk_tile = [&](int kbuf, f32x16& s0_, f32x16& s1_) {
+    uint32_t ka = lds0 + kbuf * PF_KTILE + k_lane;
+    asm volatile("" : "+v"(ka));
+    const lds_char* kb = (const lds_char*)(uintptr_t)ka;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s0_[i] = 0.f, s1_[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const s16x8 a0 = *reinterpret_cast<const __attribute__((address_space(3))) s16x8*>(kb + 32 * s);
+      const s16x8 a1 = *reinterpret_cast<const __attribute__((address_space(3))) s16x8*>(kb + 32 * s + 32 * PF_KSTR);
+      s0_ = mfma32<T>(a0, qf[s], s0_);
+      s1_ = mfma32<T>(a1, qf[s], s1_);
+    }
+  };
+
   kr0 = kr1 = vr0 = vr1 = make_uint4(0, 0, 0, 0);
   gload(0);
-  lstore(0);
+  lstore(0, 0);
+  if (ntiles > 1) gload(1);
+  lds_barrier();
+  f32x16 sc0, sc1;  // raw logits of the current tile (keys 0-31 / 32-63)
+  qk_tile(0, sc0, sc1);
+  float mx_raw = tile_max(sc0, sc1);
+  if (ntiles > 1) lstore(1, 1);
   lds_barrier();
 
+  int vcur = 0;  // t % 3
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = (dbg & 1) ? 0 : (t & 1);
-    if (t + 1 < ntiles && !(dbg & 1)) gload(t + 1);
-    const char* kb = smem + buf * 2 * PF_TILE_BYTES;
-    const char* vb = kb + PF_TILE_BYTES;
+    if (t + 2 < ntiles) gload(t + 2);
 
-    // ---- S^T = K Q^T, two 32-key blocks ------------------------------------------------------------------------
-    f32x16 sacc[2];
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[kb2][i] = 0.f;
-      if (!(dbg & 8)) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint4 a = *reinterpret_cast<const uint4*>(kb + k_off(kb2 * 32 + r, 2 * s + h));
-          sacc[kb2] = mfma32<T>(__builtin_bit_cast(s16x8, a), qf[s], sacc[kb2]);
-        }
-      }
-    }
+    const int vnext2 = vcur == 0 ? 2 : vcur - 1;  // (t + 2) % 3
+
     const bool cached = t < ntc;
     const int j0 = cached ? t * PF_KT : (t - ntc) * PF_KT;
     const int count = cached ? min(PF_KT, Lc - j0) : min(PF_KT, la_vis - j0);
     const bool need_mask = count < PF_KT || (!cached && j0 + PF_KT - 1 > m0);  // wave-uniform
-    // max over the RAW logits (scale > 0 commutes with max), then p = exp2(s*c - m*c): one FMA per logit
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
+    if (need_mask) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        if (need_mask) {
-          const int kk = kb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const bool vis = kk < count && (cached || (j0 + kk) <= tok);
-          sacc[kb2][i] = vis ? sacc[kb2][i] : -INFINITY;
-        }
-        mx = fmaxf(mx, sacc[kb2][i]);
+        const int kk = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const bool vis0 = kk < count && (cached || (j0 + kk) <= tok);
+        const bool vis1 = kk + 32 < count && (cached || (j0 + kk + 32) <= tok);
+        sc0[i] = vis0 ? sc0[i] : -INFINITY;
+        sc1[i] = vis1 ? sc1[i] : -INFINITY;
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+    // max over the RAW logits (scale > 0 commutes with max), then p = exp2(s*c - m*c): one FMA per logit.
+    // The unmasked max was computed next to the previous tile's PV MFMAs; masked tiles (rare) redo it here.
+    if (need_mask) mx_raw = tile_max(sc0, sc1);
+    const float mx = mx_raw * scale_log2e;
     const float m_new = fmaxf(m_run, mx);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     const bool grew = m_new > m_run;  // per query; rescale O only when some query of the wave saw a new max
@@ -223,7 +285,11 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
         for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
     }
 
-    // ---- P = exp2(S c - m), packed to the model dtype; O^T += V^T P^T ------------------------------------------
+    // ---- S(t+1) = K(t+1) Q^T  (MFMA)   ||   P(t) = exp2(S(t) c - m) packed to the model dtype  (VALU) -----------
+    // On the last tile this recomputes an old K tile; the result is never used.
+    f32x16 sn0, sn1;
+    qk_tile((t + 1) & 1, sn0, sn1);
+
     float psum = 0.f;
     s16x8 pf[4];
 #pragma unroll
@@ -233,12 +299,10 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
         uint32_t w[4];
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-          float p0 = fmaf(sacc[kb2][8 * s2 + 2 * jp], scale_log2e, -m_safe);
-          float p1 = fmaf(sacc[kb2][8 * s2 + 2 * jp + 1], scale_log2e, -m_safe);
-          if (!(dbg & 2)) {
-            p0 = __builtin_amdgcn_exp2f(p0);
-            p1 = __builtin_amdgcn_exp2f(p1);
-          }
+          const float x0 = kb2 ? sc1[8 * s2 + 2 * jp] : sc0[8 * s2 + 2 * jp];
+          const float x1 = kb2 ? sc1[8 * s2 + 2 * jp + 1] : sc0[8 * s2 + 2 * jp + 1];
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(x0, scale_log2e, -m_safe));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(x1, scale_log2e, -m_safe));
           w[jp] = pack2<T>(p0, p1);
           // row sum from the fp32 probabilities, P itself rounded to the model dtype (reference :398-400)
           psum += p0 + p1;
@@ -247,26 +311,29 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
       }
     }
     l_run = l_run * alpha + psum;
-    if (!(dbg & 4)) {
+
+    // ---- O^T += V(t)^T P(t)^T ------------------------------------------------------------------------------------
+    uint32_t va = lds0 + 2 * PF_KTILE + vcur * PF_VTILE + v_lane;
+    asm volatile("" : "+v"(va));
+    const lds_char* vb = (const lds_char*)(uintptr_t)va;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        // key rows of this k-step start at (ks>>1)*32 + (ks&1)*16: a multiple of 16 rows, so it does not touch
-        // the swizzle bits ((row&3), (row>>2)&3) and is a pure byte offset
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const int r0 = (ks >> 1) * 32 + (ks & 1) * 16 + 4 * (gi >> 1);  // first key row of this lane group's block
-          const int c0 = (db * 2 + (gi & 1)) * 2;                         // first 16-byte chunk of its 16 columns
-          const uint32_t a0 = v_off(r0 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
-          const uint32_t a1 = v_off(r0 + 8 + tq, c0 + (tp >> 1)) + 8 * (tp & 1);
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a1));
-          const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          oacc[db] = mfma32<T>(a, pf[ks], oacc[db]);
-        }
+      for (int db = 0; db < DB; ++db) {
+        const uint32_t a0 = ((ks >> 1) * 32 + (ks & 1) * 16) * PF_VSTR + 64 * db;  // immediate
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a0));
+        const s16x4 hi =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + a0 + 8 * PF_VSTR));
+        const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[db] = mfma32<T>(a, pf[ks], oacc[db]);
       }
     }
-    if (t + 1 < ntiles && !(dbg & 1)) lstore(buf ^ 1);
-    if (!(dbg & 16)) lds_barrier();
+    mx_raw = tile_max(sn0, sn1);  // next tile, unmasked; overlaps the PV MFMAs above
+    if (t + 2 < ntiles) lstore(t & 1, vnext2);
+    lds_barrier();
+    sc0 = sn0;
+    sc1 = sn1;
+    vcur = vcur == 2 ? 0 : vcur + 1;
   }
 
   // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ------------------------
@@ -359,6 +426,7 @@ extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, i
   if (total_tokens == 0 || max_seqlen_q <= 0) return CVLLM_OK;
   // 16-byte vector loads: every row start must be 16-byte aligned
   if ((sq_n % 8) || (sk_n % 8) || (sk_h % 8) || (sv_n % 8) || (sv_h % 8)) return CVLLM_ERR_SHAPE;
+  if (sk_n < 0 || sv_n < 0 || sk_n > 0x7fffffff || sv_n > 0x7fffffff) return CVLLM_ERR_SHAPE;  // 32-bit row strides in the kernel
   const int G = HQ / HKV;
   hipStream_t st = (hipStream_t)stream;
 #define PF_D(T_, D_)                                                                                              \
