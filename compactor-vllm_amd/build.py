@@ -17,6 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "compactor_vllm_amd", "libcvllm_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# prefill_attn.hip: row maxima over MFMA results; with NaNs honoured hipcc canonicalises every operand (v_max x,x)
+FILE_FLAGS = {"prefill_attn.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc() -> str:
@@ -47,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -54,12 +54,11 @@ static_assert(PF_SMEM >= 8 * 32 * PF_OSTRIDE, "O staging image must fit");
 //   K: lanes r = 0..15 of a ds_read_b128 group read rows r at the same column -> bank (68 r) % 64 = 4 r: distinct.
 //   V: a 32-lane half of ds_read_b64_tr_b16 reads 4 rows x 64 contiguous bytes -> row shift 80 % 64 = 16 banks.
 
-// max(a, b, c) without the v_max x,x canonicalisation hipcc puts in front of every fmaxf of an MFMA result
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
+// max(a, b, c).  This file is built with -fno-honor-nans (build.py): without it hipcc puts a v_max x,x
+// canonicalisation in front of every fmaxf of an MFMA result (3 VALU per pair instead of 1 v_max3 per two values).
+// NOT inline asm: hipcc's hazard recogniser does not see an asm statement as a VALU read of an MFMA result and
+// leaves out the wait states the read needs - stale maxima, run-to-run different roundings.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 // row max of one query over the wave's 64 keys: 32 in-lane values, then the partner lane (l ^ 32)
 __device__ __forceinline__ float tile_max(const f32x16& a, const f32x16& b) {
   float m0 = max3(a[0], a[1], a[2]), m1 = max3(b[0], b[1], b[2]);

@@ -97,3 +97,42 @@ def test_prefill_c1_shape_4k(dev):
     ones = torch.ones_like(v).to(dev)
     out1 = causal_sparse_varlen_with_cache(q.to(dev), k.to(dev), ones, *args).cpu().float()
     assert torch.allclose(out1, torch.ones_like(out1), atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_prefill_deterministic_and_large_logits(dev, dtype):
+    """Two launches on the same inputs are bit-identical (the running max is carried across tiles in registers:
+    a stale read would only change roundings), also while another stream keeps the GPU busy; logits that jump
+    by orders of magnitude between tiles (scaled q rows) stay finite and match the oracle."""
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    B, HQ, HKV, D, PS = 2, 8, 2, 128, 128
+    g = torch.Generator().manual_seed(99)
+    lens = torch.tensor([[70, 0], [200, 131]], dtype=torch.int32)
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=5)
+    append = [513, 129]
+    cu = torch.tensor([0, 513, 642], dtype=torch.int32)
+    N = 642
+    q = torch.randn(N, HQ, D, generator=g)
+    q[::7] *= 6.0  # every 7th query: logits ~ 6x larger -> the row max moves a lot from tile to tile
+    k = torch.randn(N, HKV, D, generator=g)
+    k[300:310] *= 4.0
+    v = torch.randn(N, HKV, D, generator=g)
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    args = (kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), cu.to(dev), max(append), int(lens.max()),
+            HKV, PS, scale)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out1 = causal_sparse_varlen_with_cache(qd, kd, vd, *args)
+    side = torch.cuda.Stream()
+    junk = torch.randn(2048, 2048, device=dev)
+    with torch.cuda.stream(side):
+        for _ in range(8):
+            junk = junk @ junk * 1e-3
+    out2 = causal_sparse_varlen_with_cache(qd, kd, vd, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2)
+    assert torch.isfinite(out1.float()).all()
+    ref = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale)
+    d = (out1.cpu().float() - ref.float()).abs().max()
+    assert torch.allclose(out1.cpu().float(), ref.float(), rtol=1e-6, atol=tol(dtype)), d

@@ -250,10 +250,138 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const uint16_t* __restr
   }
 }
 
+
+// Pipelined decode GEMV (one x row): a wave owns RPW weight rows and walks K in batches of UN 16-byte chunks per
+// lane, with batch b+1's loads issued before batch b's dot products, and batch 0 issued BEFORE the x prologue
+// (norm / SiLU / copy into LDS), whose latency then hides behind the first HBM round trip.  One row group per wave
+// (grid = N / (4 RPW)): N = 4096 gives 512 workgroups = 8 waves per CU with 8 loads of 1 KiB in flight each.
+//   MODE 0: x as given   MODE 1: x = rmsnorm(h + delta) * nw (block 0 writes h_out)   MODE 2: x = silu(gu[:K]) * gu[K:]
+template <int MODE, int RPW, int UN>
+__global__ __launch_bounds__(256) void gemv2_kernel(const uint16_t* __restrict__ W, const uint16_t* __restrict__ h,
+                                                    uint16_t* __restrict__ h_out, const uint16_t* __restrict__ delta,
+                                                    const uint16_t* __restrict__ nw, const uint16_t* __restrict__ gu,
+                                                    uint16_t* __restrict__ y, int N, int K, float eps) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_x[];  // [K]
+  __shared__ float s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  const int nb = K / (8 * 64 * UN);  // batches; K % (512 UN) == 0 checked on the host
+  const uint16_t* wrow[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) wrow[r] = W + (size_t)min(row0 + r, N - 1) * K + lane * 8;
+  u32x4_t cur[RPW][UN], nxt[RPW][UN];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      cur[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[r] + u * 512));
+
+  if (MODE == 1) {
+    float ss = 0.f;
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      uint4 hv = *reinterpret_cast<const uint4*>(h + i);
+      uint16_t* hp = reinterpret_cast<uint16_t*>(&hv);
+      if (delta) {
+        uint4 dv = *reinterpret_cast<const uint4*>(delta + i);
+        const uint16_t* dp = reinterpret_cast<const uint16_t*>(&dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hp[j] = f2bf(bf2f(hp[j]) + bf2f(dp[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf2f(hp[j]);
+        ss += f * f;
+      }
+      *reinterpret_cast<uint4*>(s_x + i) = hv;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) s_part[wave] = ss;
+    __syncthreads();
+    const float inv = rsqrtf((s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)K + eps);
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      uint4 hv = *reinterpret_cast<const uint4*>(s_x + i);
+      uint4 wv = *reinterpret_cast<const uint4*>(nw + i);
+      if (blockIdx.x == 0) *reinterpret_cast<uint4*>(h_out + i) = hv;  // residual stream, written once
+      uint16_t* hp = reinterpret_cast<uint16_t*>(&hv);
+      const uint16_t* wp = reinterpret_cast<const uint16_t*>(&wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hp[j] = f2bf(bf2f(hp[j]) * inv * bf2f(wp[j]));
+      *reinterpret_cast<uint4*>(s_x + i) = hv;
+    }
+  } else if (MODE == 2) {
+    for (int i = tid * 8; i < K; i += 256 * 8) {
+      uint4 gv = *reinterpret_cast<const uint4*>(gu + i);
+      uint4 uv = *reinterpret_cast<const uint4*>(gu + K + i);
+      uint16_t* gp = reinterpret_cast<uint16_t*>(&gv);
+      const uint16_t* up = reinterpret_cast<const uint16_t*>(&uv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = bf2f(gp[j]);
+        gp[j] = f2bf(g / (1.f + __expf(-g)) * bf2f(up[j]));
+      }
+      *reinterpret_cast<uint4*>(s_x + i) = gv;
+    }
+  } else {
+    for (int i = tid * 8; i < K; i += 256 * 8) *reinterpret_cast<uint4*>(s_x + i) = *reinterpret_cast<const uint4*>(h + i);
+  }
+  __syncthreads();
+
+  float acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    if (b + 1 < nb) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          nxt[r][u] = __builtin_nontemporal_load(
+              reinterpret_cast<const u32x4_t*>(wrow[r] + (size_t)(b + 1) * UN * 512 + u * 512));
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(s_x + (b * UN + u) * 512 + lane * 8);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        float a = acc[r];
+        a = dot2bf(cur[r][u].x, xv.x, a);
+        a = dot2bf(cur[r][u].y, xv.y, a);
+        a = dot2bf(cur[r][u].z, xv.z, a);
+        a = dot2bf(cur[r][u].w, xv.w, a);
+        acc[r] = a;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) cur[r][u] = nxt[r][u];
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const float t = wave_sum(acc[r]);
+    if (lane == 0 && row0 + r < N) y[row0 + r] = f2bf(t);
+  }
+}
+
+constexpr int G2_RPW = 2, G2_UN = 4;
+static bool gemv2_ok(int N, int K) { return K % (512 * G2_UN) == 0 && (size_t)K * 2 <= 64 * 1024 && N <= 8192 * 4 * G2_RPW; }
+template <int MODE>
+static void gemv2_launch(const void* W, const void* h, void* h_out, const void* delta, const void* nw, const void* gu,
+                         void* y, int N, int K, float eps, void* stream) {
+  const int blocks = (N + 4 * G2_RPW - 1) / (4 * G2_RPW);
+  hipLaunchKernelGGL((gemv2_kernel<MODE, G2_RPW, G2_UN>), dim3(blocks), dim3(256), (size_t)K * 2, (hipStream_t)stream,
+                     (const uint16_t*)W, (const uint16_t*)h, (uint16_t*)h_out, (const uint16_t*)delta,
+                     (const uint16_t*)nw, (const uint16_t*)gu, (uint16_t*)y, N, K, eps);
+}
+
 extern "C" int shell_gemv_norm(const void* W, const void* h, void* h_out, const void* delta, const void* nw, void* y,
                                int N, int K, float eps, void* stream) {
   if (h == h_out) return -1;
   if (K % 8 || (size_t)K * 2 > 64 * 1024) return -1;
+  if (gemv2_ok(N, K)) {
+    gemv2_launch<1>(W, h, h_out, delta, nw, nullptr, y, N, K, eps, stream);
+    return 0;
+  }
   int blocks = (N + 15) / 16;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL((gemv_fused_kernel<1, 4>), dim3(blocks), dim3(256), (size_t)K * 2, (hipStream_t)stream,
@@ -263,6 +391,10 @@ extern "C" int shell_gemv_norm(const void* W, const void* h, void* h_out, const 
 }
 extern "C" int shell_gemv_silu(const void* W, const void* gu, void* y, int N, int K, void* stream) {
   if (K % 8 || (size_t)K * 2 > 64 * 1024) return -1;
+  if (gemv2_ok(N, K)) {
+    gemv2_launch<2>(W, nullptr, nullptr, nullptr, nullptr, gu, y, N, K, 0.f, stream);
+    return 0;
+  }
   int blocks = (N + 15) / 16;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL((gemv_fused_kernel<2, 4>), dim3(blocks), dim3(256), (size_t)K * 2, (hipStream_t)stream,
@@ -275,6 +407,10 @@ extern "C" int shell_gemv(const void* W, const void* x, void* y, int B, int N, i
   if (K % 8 || B < 1 || B > 4) return -1;
   const size_t smem = (size_t)B * K * 2;
   if (smem > 64 * 1024) return -1;
+  if (B == 1 && gemv2_ok(N, K)) {
+    gemv2_launch<0>(W, x, nullptr, nullptr, nullptr, nullptr, y, N, K, 0.f, stream);
+    return 0;
+  }
   constexpr int RPW = 4;
   int blocks = (N + 4 * RPW - 1) / (4 * RPW);
   if (blocks > 2048) blocks = 2048;
