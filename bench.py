@@ -52,10 +52,15 @@ def hip_events(n):
     return hip, evs
 
 
-def roofline_decode_attn(model, state, workload, rounds=3):
-    """Achieved HBM GB/s of the decode-attention stage-1 kernel on the REAL post-prefill cache of every layer
-    (distinct memory per layer => cold L2 / Infinity Cache, like inside a decode step).  HIP events are
-    recorded by the library right before/after the stage-1 launch on the launch stream."""
+def roofline_decode_attn(model, state, workload, rounds=5):
+    """Achieved HBM GB/s of decode_fused_kernel on the REAL post-prefill cache of every layer (distinct memory per
+    layer, 2.2 GB per pass => cold L2 / Infinity Cache, like inside a decode step).  One HIP graph holds the kernel's
+    launches of all layers back to back (the merge kernel is switched off through the library's debug hook, so
+    nothing else runs in between); `rounds` replays of it are queued on the current stream between ONE pair of HIP
+    events recorded on that stream, and per-launch time = elapsed / (rounds * layers).  That includes the dispatch gap
+    between consecutive launches, so it is an upper bound of rocprofv3's kernel duration (profiles/) and the reported
+    fraction a lower bound.  (Event-record nodes captured INSIDE a graph do not refresh the events' timestamps on
+    this ROCm - hipEventElapsedTime keeps returning the last eager recording - so the events stay outside.)"""
     from compactor_vllm_amd import _lib
     from compactor_vllm_amd.attention.sparse_decode_kernel import head_sparse_decode_attention
 
@@ -64,11 +69,10 @@ def roofline_decode_attn(model, state, workload, rounds=3):
     B = bm.numel()
     q = torch.randn(B, cfg.heads, cfg.head_dim, device=dev, dtype=torch.bfloat16)
     L = _lib.lib()
-    L.cvllm_debug_set_decode_events.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.cvllm_debug_set_decode_stage2.argtypes = [ctypes.c_int]
     nl = cfg.layers
-    hip, evs = hip_events(2 * nl)
     elt = 2
-    durs, bytes_alg = [], []
+    bytes_alg = []
     lens_all = [a.bh_seq_lens.index_select(0, bm).contiguous() for a in model.attn]
     for lens in lens_all:
         rows = int(lens.sum().item())
@@ -76,37 +80,73 @@ def roofline_decode_attn(model, state, workload, rounds=3):
 
     def one_pass():
         for li, a in enumerate(model.attn):
-            L.cvllm_debug_set_decode_events(evs[2 * li], evs[2 * li + 1])
             head_sparse_decode_attention(q, a.k_cache, a.v_cache, lens_all[li], a.page_table, bm, cfg.kv_heads,
                                          a.page_size)
-            L.cvllm_debug_set_decode_events(None, None)
 
     one_pass()  # warm-up (workspace allocation)
     torch.cuda.synchronize()
-    # One HIP graph holding all layers' launches with their event-record nodes: replayed like a decode step, so
-    # the event spans do not include host launch latency.
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        one_pass()
-    for rnd in range(rounds + 1):
+    L.cvllm_debug_set_decode_stage2(0)
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_pass()
+    finally:
+        L.cvllm_debug_set_decode_stage2(1)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
         graph.replay()
-        torch.cuda.synchronize()
-        if rnd == 0:
-            continue
-        for li in range(nl):
-            ms = ctypes.c_float()
-            hip.hipEventElapsedTime(ctypes.byref(ms), evs[2 * li], evs[2 * li + 1])
-            durs.append(ms.value * 1e-3)
-    for e in evs:
-        hip.hipEventDestroy(e)
-    avg_s = sum(durs) / len(durs)
+    e1.record()
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) * 1e-3 / (rounds * nl)
     avg_bytes = sum(bytes_alg) / len(bytes_alg)
     achieved = avg_bytes / avg_s / 1e9
     return {"bound": "hbm", "kernel": "decode_fused_kernel", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": pmc_traffic(workload, int(avg_bytes)),
             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
-            "timing": "HIP events recorded around the kernel node inside a replayed HIP graph of all layers"}
+            "timing": f"one HIP event pair on the launch stream around {rounds} queued replays of a HIP graph holding "
+                      f"{nl} back-to-back launches (one per layer's cache), divided by {rounds * nl}; includes the "
+                      f"inter-launch dispatch gap"}
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def roofline_prefill_attn(model, ctx, rounds=3):
+    """Second roofline object: the prefill attention kernel (MFMA-bound) at the workload's context length on
+    synthetic q/k/v of the model's head shape with an empty cache; causal FLOPs = 4 * S^2 * D * HQ / 2 per launch,
+    timed with events on the current stream (the stream the kernel is launched on) around `rounds` launches."""
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    cfg, dev = model.cfg, model.dev
+    a = model.attn[0]
+    q = torch.randn(ctx, cfg.heads, cfg.head_dim, device=dev, dtype=torch.bfloat16)
+    k = torch.randn(ctx, cfg.kv_heads, cfg.head_dim, device=dev, dtype=torch.bfloat16)
+    v = torch.randn(ctx, cfg.kv_heads, cfg.head_dim, device=dev, dtype=torch.bfloat16)
+    lens = torch.zeros(1, cfg.kv_heads, dtype=torch.int32, device=dev)
+    bm = torch.ones(1, dtype=torch.int32, device=dev)
+    cu = torch.tensor([0, ctx], dtype=torch.int32, device=dev)
+
+    def run():
+        return causal_sparse_varlen_with_cache(q, k, v, a.k_cache, a.v_cache, lens, a.page_table, bm, cu, ctx, 0,
+                                               cfg.kv_heads, a.page_size)
+
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / rounds
+    flops = 4.0 * ctx * ctx * cfg.head_dim * cfg.heads / 2
+    tf = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "prefill_attn_kernel", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops_per_launch": flops}
 
 
 def pmc_traffic(workload, alg_bytes):
@@ -268,6 +308,7 @@ def main():
         state = {}
         step(state)  # one more generate whose cache stays allocated: the roofline leg runs on the real cache
         result["roofline"] = roofline_decode_attn(model, state, args.workload)
+        result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
         for bi in state["rows"]:
             model.cache.free_batch(bi)
         if world == 1 and not args.no_cpu_baseline:

@@ -18,7 +18,10 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "compactor_vllm_amd", "libcvllm_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # prefill_attn.hip: row maxima over MFMA results; with NaNs honoured hipcc canonicalises every operand (v_max x,x)
-FILE_FLAGS = {"prefill_attn.hip": ["-fno-honor-nans"]}
+# decode_attn.hip: first kernel arguments preloaded into SGPRs at wave launch (the decode kernel's fixed cost is a
+# chain of dependent memory round trips; the kernarg fetch is the first of them)
+FILE_FLAGS = {"prefill_attn.hip": ["-fno-honor-nans"],
+              "decode_attn.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 
 
 def _hipcc() -> str:

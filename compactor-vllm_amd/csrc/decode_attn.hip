@@ -275,16 +275,37 @@ struct VmWait;
   };
 CVLLM_VMWAIT(0) CVLLM_VMWAIT(8) CVLLM_VMWAIT(12) CVLLM_VMWAIT(16) CVLLM_VMWAIT(24) CVLLM_VMWAIT(32)
 
+// -DCVLLM_DEC_TS (tools/decode_ts.py builds a separate debug library with it): wave 0 of workgroup 0 records s_memtime
+// at the phase boundaries of decode_fused_kernel.  Not compiled into libcvllm_hip.so.
+#ifdef CVLLM_DEC_TS
+__device__ unsigned long long g_dec_ts[16];
+#define DEC_TS(i)                                                                    \
+  do {                                                                               \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_ts[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DEC_TS(i) \
+  do {            \
+  } while (0)
+#endif
+
 constexpr int DEC_PGREGS = 8;       // page ids cached in registers: 8 x 64 pages
 constexpr int DEC_MAX_SPLITS = 256;
 
 template <typename T, int D, int G, int NW, int NL, int R>
 __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
-    const uint16_t* __restrict__ q, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
-    uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
-    int* __restrict__ seq_lens, const int* __restrict__ page_table, const int* __restrict__ bmap,
-    const uint16_t* __restrict__ key_new, const uint16_t* __restrict__ val_new, int64_t sk_b, int64_t sk_h,
-    int64_t sv_b, int64_t sv_h, int HKV, int PS, int NLP, int S, float scale, int lens_by_row, int reserved) {
+    // argument order = order of first use: the leading 14 dwords are preloaded into SGPRs at wave launch
+    // (-mllvm -amdgpu-kernarg-preload-count=16, build.py), the rest is fetched in ONE batch at the top (below)
+    const uint16_t* __restrict__ q, const int* __restrict__ bmap, int* __restrict__ seq_lens,
+    const int* __restrict__ page_table, const uint16_t* __restrict__ key_new, const uint16_t* __restrict__ val_new,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int HKV, int PS, int NLP, int S, float scale,
+    int lens_by_row, int reserved, int64_t sk_b, int64_t sk_h, int64_t sv_b, int64_t sv_h,
+    uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse) {
+  // hipcc fetches kernel arguments lazily, one dependent s_load + wait in front of each first use (four round trips
+  // in this kernel's prologue); naming them all here puts every fetch into one clause.
+  asm volatile("" ::"s"(vc), "s"(HKV), "s"(PS), "s"(NLP), "s"(S), "s"(scale), "s"(lens_by_row), "s"(reserved));
+  asm volatile("" ::"s"(sk_b), "s"(sk_h), "s"(sv_b), "s"(sv_h), "s"(out), "s"(part_o), "s"(part_lse));
+  DEC_TS(0);
   constexpr int LPR = D / 8;
   constexpr int RPL = 64 / LPR;
   constexpr int UR = RPL * NL;
@@ -295,10 +316,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   static_assert(2 * NL * P <= 60, "vmcnt is a 6-bit counter");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [NW][R][UNIT_BYTES] rings | s_acc[NW][G][D] f32 | s_m[NW][G] | s_l[NW][G]
-  float* s_acc = reinterpret_cast<float*>(smem + NW * R * UNIT_BYTES);
-  float* s_m = s_acc + NW * G * D;
-  float* s_l = s_m + NW * G;
+  // layout: [NW][R][UNIT_BYTES] rings; after the loop each wave's ring doubles as its merge staging area
 
   const int bid = blockIdx.x;
   const int s = bid % S;
@@ -312,8 +330,28 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   const int c = lane / LPR;
   const int dl = lane % LPR;
 
+  // q and the new K/V row depend on (b, h) only: issued first, in flight together with the batch_mapping -> length /
+  // page-table chain below instead of after it (one dependent memory round trip less in front of the first K/V byte;
+  // the fixed ~6 us of this kernel is that chain).  Every split loads the new row; its owner uses it.
+  uint4 qf[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+    qf[g] = *reinterpret_cast<const uint4*>(q + ((size_t)b * HQ + h * G + g) * D + dl * 8);
+  // unconditional loads (a "load or zero" select would need the data, i.e. a wait, right here): without an appended
+  // row the pointers fall back to q and the values are never used
+  const uint16_t* q0 = q + ((size_t)b * HQ + h * G) * D + dl * 8;
+  const uint16_t* knp = key_new != nullptr ? key_new + b * sk_b + h * sk_h + dl * 8 : q0;
+  const uint16_t* vnp = key_new != nullptr ? val_new + b * sv_b + h * sv_h + dl * 8 : q0;
+  asm volatile("" : "+v"(knp), "+v"(vnp));  // opaque: hipcc otherwise folds the fallback into "wait for q, then copy"
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) const u32x4_t gptr_t;  // global, not flat: flat loads also count in lgkmcnt
+  const u32x4_t kn4 = *(gptr_t*)(uintptr_t)knp, vn4 = *(gptr_t*)(uintptr_t)vnp;
+  uint4 knew = make_uint4(kn4[0], kn4[1], kn4[2], kn4[3]);
+  uint4 vnew = make_uint4(vn4[0], vn4[1], vn4[2], vn4[3]);
   const int bt = bmap[b];
   const int lidx = lens_by_row ? bt * HKV + h : bh;
+  DEC_TS(1);
+  const int L_old = seq_lens[lidx];  // issued before the page-id loads, consumed after them
   const bool append = key_new != nullptr && bt != reserved;
   // Page ids: when the whole row of the page table fits the register cache (NLP <= 512 pages = 64K rows at
   // PS 128) it is loaded by ABSOLUTE logical page, which depends on batch_mapping only - so it is in flight
@@ -329,8 +367,8 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       pgreg[j] = i < NLP ? pt[i] : 0;
     }
   }
-  const int L_old = seq_lens[lidx];
   const int L = (key_new != nullptr && bt == reserved) ? 0 : L_old + (append ? 1 : 0);
+  DEC_TS(2);
 
   int per = (L + S - 1) / S;
   per = (per + ROUND - 1) / ROUND * ROUND;
@@ -353,15 +391,6 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       }
     }
     const int pg_bias = pg_abs ? lp0 : 0;  // page_of() takes a page index relative to the split
-    uint4 qf[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-      qf[g] = *reinterpret_cast<const uint4*>(q + ((size_t)b * HQ + h * G + g) * D + dl * 8);
-    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
-    if (owns_new) {
-      knew = *reinterpret_cast<const uint4*>(key_new + b * sk_b + h * sk_h + dl * 8);
-      vnew = *reinterpret_cast<const uint4*>(val_new + b * sv_b + h * sv_h + dl * 8);
-    }
     // Retire every ordinary load before the first LDS-DMA and hide the registers' origin from hipcc: it would
     // otherwise wait vmcnt(0) at each later use of q / page ids, draining the ring every iteration.
 #pragma unroll
@@ -371,6 +400,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     asm volatile("" : "+v"(knew.x), "+v"(knew.y), "+v"(knew.z), "+v"(knew.w));
     asm volatile("" : "+v"(vnew.x), "+v"(vnew.y), "+v"(vnew.z), "+v"(vnew.w));
 
+    DEC_TS(3);
     float m[G], l[G], acc[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -415,6 +445,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
 #pragma unroll
     for (int j = 0; j < P; ++j)
       if (j < njw) issue(j);
+    DEC_TS(4);
 
     for (int j = 0; j < njw; ++j) {
       if (j + P < njw) {
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       }
     }
 
+    DEC_TS(5);
     if (owns_new) {  // write the appended row into the paged cache (one 16-lane group owns it)
       const int u = (L_old - start) / UR;  // unit of the new row
       if ((u % NW) == wave && c == ((L_old - start) % UR) % RPL) {
@@ -514,55 +546,64 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       }
     }
 
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float mo = __shfl_xor(m[g], off, 64);
-        const float lo = __shfl_xor(l[g], off, 64);
-        const float mx = fmaxf(m[g], mo);
-        const float mxs = (mx == -INFINITY) ? 0.f : mx;
-        const float a0 = __expf(m[g] - mxs), a1 = __expf(mo - mxs);
-        l[g] = l[g] * a0 + lo * a1;
-        m[g] = mx;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          const float ao = __shfl_xor(acc[g][d], off, 64);
-          acc[g][d] = acc[g][d] * a0 + ao * a1;
-        }
-      }
-    }
-    if (c == 0) {
+    // ---- merge of the NW * RPL partial softmax states of this split ---------------------------------------------
+    // Every 16-lane row group (RPL per wave) holds its own (m, l, acc).  They are NOT combined by cross-lane
+    // shuffles (two rounds of 10 dependent ds_bpermute per head: 2,600 cycles measured with s_memtime, more than the
+    // whole streaming phase of a 16-row split) but staged once into the wave's own, now idle, ring region and reduced
+    // by the output pass below, which needed LDS and a barrier for the cross-wave merge anyway.
+    constexpr int NPART = NW * RPL;
+    constexpr int ST_ML = RPL * G * D * 4;  // byte offset of the (m, l) pairs inside a wave's staging area
+    static_assert(ST_ML + RPL * G * 8 <= R * UNIT_BYTES, "staging area must fit the wave's ring");
+    {
+      char* st = ring;  // all of this wave's DMA has landed and been read (tail iterations drained vmcnt / lgkmcnt)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (dl == 0) {
-          s_m[wave * G + g] = m[g];
-          s_l[wave * G + g] = l[g];
-        }
-#pragma unroll
-        for (int d = 0; d < 8; ++d) s_acc[(wave * G + g) * D + dl * 8 + d] = acc[g][d];
+        float4* dst = reinterpret_cast<float4*>(st + ((c * G + g) * D + dl * 8) * 4);
+        dst[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        dst[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+        if (dl == 0) *reinterpret_cast<float2*>(st + ST_ML + (c * G + g) * 8) = make_float2(m[g], l[g]);
       }
     }
+    DEC_TS(6);
     __syncthreads();
-    for (int idx = tid; idx < G * D; idx += NW * 64) {
-      const int g = idx / D, d = idx % D;
-      float M = s_m[g];
+    DEC_TS(7);
+    // output pass: a thread owns OPT consecutive dims of ONE head, so the NPART weights exp(m_p - M) are computed once
+    // per thread (wave-uniform head -> broadcast LDS reads)
+    constexpr int OPT = (G * D >= NW * 64) ? (G * D) / (NW * 64) : 1;
+    static_assert((G * D) % OPT == 0 && D % OPT == 0, "output pass tiling");
+    if (tid * OPT < G * D) {
+      const int g = (tid * OPT) / D, d0 = (tid * OPT) % D;
+      float2 ml[NPART];
+      float M = -INFINITY;
 #pragma unroll
-      for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w * G + g]);
-      float num = 0.f, den = 0.f;
+      for (int p_ = 0; p_ < NPART; ++p_) {
+        const char* st = smem + (p_ / RPL) * (R * UNIT_BYTES);
+        ml[p_] = *reinterpret_cast<const float2*>(st + ST_ML + ((p_ % RPL) * G + g) * 8);
+        M = fmaxf(M, ml[p_].x);  // finite: group 0 of wave 0 always owns a valid row
+      }
+      float num[OPT], den = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const float a = __expf(s_m[w * G + g] - M);  // M finite: wave 0 always owns a valid row
-        num += a * s_acc[(w * G + g) * D + d];
-        den += a * s_l[w * G + g];
+      for (int o = 0; o < OPT; ++o) num[o] = 0.f;
+#pragma unroll
+      for (int p_ = 0; p_ < NPART; ++p_) {
+        const char* st = smem + (p_ / RPL) * (R * UNIT_BYTES);
+        const float a = __expf(ml[p_].x - M);
+        den = fmaf(a, ml[p_].y, den);
+        const float* ap = reinterpret_cast<const float*>(st + (((p_ % RPL) * G + g) * D + d0) * 4);
+#pragma unroll
+        for (int o = 0; o < OPT; ++o) num[o] = fmaf(a, ap[o], num[o]);
       }
-      const float o = num / den;
-      if (S == 1) {
-        out[((size_t)b * HQ + h * G + g) * D + d] = to16<T>(o);
-      } else {
-        po[g * D + d] = o;
-        if (d == 0) pl[g] = M + __logf(den);
+      const float inv = 1.f / den;
+#pragma unroll
+      for (int o = 0; o < OPT; ++o) {
+        const float ov = num[o] * inv;
+        if (S == 1) {
+          out[((size_t)b * HQ + h * G + g) * D + d0 + o] = to16<T>(ov);
+        } else {
+          po[g * D + d0 + o] = ov;
+        }
       }
+      if (S != 1 && d0 == 0) pl[g] = M + __logf(den);
     }
   } else {  // empty split (covers L == 0 and RESERVED rows)
     if (S == 1) {
@@ -575,11 +616,19 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   // S == 1: this is the only workgroup of (b,h) and it has consumed L_old -> publish the new length here.
   // S > 1: the merge kernel (stream-ordered after every stage-1 workgroup) publishes it.
   if (S == 1 && append && tid == 0) seq_lens[lidx] = L_old + 1;
+  DEC_TS(8);
 }
+#ifdef CVLLM_DEC_TS
+}  // namespace cvllm
+extern "C" void cvllm_debug_read_decode_ts(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_dec_ts), sizeof(unsigned long long) * 16);
+}
+namespace cvllm {
+#endif
 
 template <int D, int G, int NW, int NL, int R>
 constexpr size_t ring_smem_bytes() {
-  return (size_t)NW * R * 2 * NL * 1024 + ((size_t)NW * G * D + 2 * NW * G) * sizeof(float) + 16;
+  return (size_t)NW * R * 2 * NL * 1024;
 }
 
 // stage 2: LSE-weighted merge of the S partials of one (b, query head)   (reference :391-435)
@@ -653,6 +702,7 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(const float* __restr
 }
 
 static hipEvent_t g_evt_start = nullptr, g_evt_stop = nullptr;  // bench.py roofline leg
+static int g_skip_stage2 = 0;                                        // bench.py roofline leg: stage-1 launches only
 
 struct DecodeArgs {
   const void *q, *key_new, *val_new;
@@ -683,12 +733,12 @@ static int launch_fused(const DecodeArgs& a) {
     attr_done = true;
   }
   if (g_evt_start) (void)hipEventRecord(g_evt_start, a.st);
-  hipLaunchKernelGGL(kern, dim3(a.B * a.HKV * a.S), dim3(NW * 64), smem, a.st, (const uint16_t*)a.q, (uint16_t*)a.kc,
-                     (uint16_t*)a.vc, (uint16_t*)a.out, part_o, part_lse, a.seq_lens, a.page_table, a.bmap,
-                     (const uint16_t*)a.key_new, (const uint16_t*)a.val_new, a.sk_b, a.sk_h, a.sv_b, a.sv_h, a.HKV,
-                     a.PS, a.NLP, a.S, a.scale, a.lens_by_row, a.reserved);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.HKV * a.S), dim3(NW * 64), smem, a.st, (const uint16_t*)a.q, a.bmap, a.seq_lens,
+                     a.page_table, (const uint16_t*)a.key_new, (const uint16_t*)a.val_new, (uint16_t*)a.kc,
+                     (uint16_t*)a.vc, a.HKV, a.PS, a.NLP, a.S, a.scale, a.lens_by_row, a.reserved, a.sk_b, a.sk_h,
+                     a.sv_b, a.sv_h, (uint16_t*)a.out, part_o, part_lse);
   if (g_evt_stop) (void)hipEventRecord(g_evt_stop, a.st);
-  if (a.S > 1)
+  if (a.S > 1 && !g_skip_stage2)
     hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(a.B * HQ), dim3(256), 0, a.st, part_o, part_lse,
                        (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, a.key_new != nullptr ? 1 : 0, a.lens_by_row,
                        a.reserved);
@@ -807,6 +857,10 @@ extern "C" void cvllm_debug_set_decode_events(void* start, void* stop) {
   g_evt_start = (hipEvent_t)start;
   g_evt_stop = (hipEvent_t)stop;
 }
+
+// bench.py: launch only decode_fused_kernel (no merge kernel; the output is then NOT an attention result) so that a
+// run of back-to-back launches times that kernel alone
+extern "C" void cvllm_debug_set_decode_stage2(int enabled) { g_skip_stage2 = enabled ? 0 : 1; }
 
 // Host restatement of num_splits_heuristic (cv/attention/sparse_decode_kernel.py:169-192).
 extern "C" int cvllm_num_splits(int total_mblocks, int max_seq_len, int num_sms, int max_splits) {
