@@ -79,7 +79,7 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
     int64_t sk_n, int64_t sk_h, int64_t sv_n, int64_t sv_h, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, uint16_t* __restrict__ out, const int* __restrict__ seq_lens,
     const int* __restrict__ page_table, const int* __restrict__ bmap, const int* __restrict__ cu, int B, int HKV,
-    int PS, int NLP, float scale_log2e, int dbg) {
+    int PS, int NLP, float scale_log2e) {
   constexpr int BM = PF_ROWS / G;  // tokens per query tile
   constexpr int KS = D / 16;       // k-steps of the QK^T product
   constexpr int DB = D / 32;       // 32-wide blocks of the head dim
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   }
 }
 
-static int g_pf_dbg = 0;  // timing experiments only (tools/microbench.py): skip phases, results are garbage
 
 template <typename T, int D, int G>
 static int launch_prefill(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n, int64_t sk_h,
@@ -385,7 +384,7 @@ static int launch_prefill(const void* q, const void* k, const void* v, int64_t s
   }
   hipLaunchKernelGGL(kern, dim3(nqt * B * HKV), dim3(PF_THREADS), PF_SMEM, st, (const uint16_t*)q, (const uint16_t*)k,
                      (const uint16_t*)v, sq_n, sk_n, sk_h, sv_n, sv_h, (const uint16_t*)kc, (const uint16_t*)vc,
-                     (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP, scale * 1.4426950408889634f, g_pf_dbg);
+                     (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP, scale * 1.4426950408889634f);
   return check_launch();
 }
 
@@ -411,7 +410,6 @@ static int prefill_dispatch_g(int G, const void* q, const void* k, const void* v
 
 using namespace cvllm;
 
-extern "C" void cvllm_debug_set_prefill(int v) { cvllm::g_pf_dbg = v; }
 
 extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n,
                                   int64_t sk_h, int64_t sv_n, int64_t sv_h, const void* k_cache, const void* v_cache,

@@ -20,14 +20,3 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _kernel_variant_from_env():
-    """CVLLM_PREFILL_DBG=<int> selects a build-internal prefill kernel variant for A/B validation (32 = staggered)."""
-    v = os.environ.get("CVLLM_PREFILL_DBG")
-    if v:
-        from compactor_vllm_amd import _lib
-
-        _lib.lib().cvllm_debug_set_prefill(int(v))
-    yield

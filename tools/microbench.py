@@ -87,8 +87,6 @@ def bench_prefill(args):
         bm = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
         cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L
         fn = lambda: causal_sparse_varlen_with_cache(q, k, v, kc, kc, lens, pt, bm, cu, L, 0, HKV, PS)
-        from compactor_vllm_amd import _lib
-        _lib.lib().cvllm_debug_set_prefill(args.variant if args.variant >= 0 else 0)
         us = time_fn(fn, iters=5, warmup=2)
         flops = 4 * D * HQ * B * (L * (L + 1) / 2)
         print(f"prefill B={B} L={L}: {us / 1e3:9.3f} ms  {flops / us / 1e6:8.1f} TFLOP/s (causal flops)", flush=True)
