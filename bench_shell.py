@@ -60,6 +60,8 @@ def shell():
         L.shell_gemv.restype = I
         L.shell_gemv_norm.argtypes = [P, P, P, P, P, P, I, I, F, P]
         L.shell_gemv_norm.restype = I
+        L.shell_gemv_norm_rope.argtypes = [P, P, P, P, P, P, I, I, F, P, P, I, P]
+        L.shell_gemv_norm_rope.restype = I
         L.shell_gemv_silu.argtypes = [P, P, P, I, I, P]
         L.shell_gemv_silu.restype = I
         for f in (L.shell_add_rmsnorm, L.shell_rope, L.shell_silu_mul):
@@ -218,16 +220,24 @@ class ModelShell:
         delta = None
         for li, L in enumerate(self.layers):
             qkv = torch.empty((1, self.qsz + 2 * self.kvsz), dtype=dt, device=dev)
-            S.shell_gemv_norm(L["wqkv"].data_ptr(), ha.data_ptr(), hb.data_ptr(),
-                              None if delta is None else delta.data_ptr(), L["n1"].data_ptr(), qkv.data_ptr(),
-                              self.qsz + 2 * self.kvsz, H, cfg.rms_eps, _st())
+            dptr = None if delta is None else delta.data_ptr()
+            fused_rope = L["qn"] is None and S.shell_gemv_norm_rope(
+                L["wqkv"].data_ptr(), ha.data_ptr(), hb.data_ptr(), dptr, L["n1"].data_ptr(), qkv.data_ptr(),
+                self.qsz + 2 * self.kvsz, H, cfg.rms_eps, positions.data_ptr(), self.rope_cs.data_ptr(),
+                self.qsz + self.kvsz, _st()) == 0
+            if not fused_rope:
+                S.shell_gemv_norm(L["wqkv"].data_ptr(), ha.data_ptr(), hb.data_ptr(), dptr, L["n1"].data_ptr(),
+                                  qkv.data_ptr(), self.qsz + 2 * self.kvsz, H, cfg.rms_eps, _st())
             ha, hb = hb, ha
             v = qkv[:, self.qsz + self.kvsz :].view(1, cfg.kv_heads, D)
-            qk = torch.empty((1, cfg.heads + cfg.kv_heads, D), dtype=dt, device=dev)
-            S.shell_rope(qkv.data_ptr(), qkv.stride(0), qk.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
-                         None if L["qn"] is None else L["qn"].data_ptr(),
-                         None if L["kn"] is None else L["kn"].data_ptr(), 1, cfg.heads + cfg.kv_heads, cfg.heads,
-                         cfg.rms_eps, _st())
+            if fused_rope:  # q and k were rotated in the GEMV's epilogue, in place in the projection buffer
+                qk = qkv[:, : self.qsz + self.kvsz].view(1, cfg.heads + cfg.kv_heads, D)
+            else:
+                qk = torch.empty((1, cfg.heads + cfg.kv_heads, D), dtype=dt, device=dev)
+                S.shell_rope(qkv.data_ptr(), qkv.stride(0), qk.data_ptr(), positions.data_ptr(),
+                             self.rope_cs.data_ptr(), None if L["qn"] is None else L["qn"].data_ptr(),
+                             None if L["kn"] is None else L["kn"].data_ptr(), 1, cfg.heads + cfg.kv_heads, cfg.heads,
+                             cfg.rms_eps, _st())
             o = self.attn[li](qk[:, : cfg.heads], qk[:, cfg.heads :], v, None)
             delta = linear(o.view(1, self.qsz), L["wo"])
             gu = torch.empty((1, 2 * I), dtype=dt, device=dev)

@@ -256,19 +256,27 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const uint16_t* __restr
 // (norm / SiLU / copy into LDS), whose latency then hides behind the first HBM round trip.  One row group per wave
 // (grid = N / (4 RPW)): N = 4096 gives 512 workgroups = 8 waves per CU with 8 loads of 1 KiB in flight each.
 //   MODE 0: x as given   MODE 1: x = rmsnorm(h + delta) * nw (block 0 writes h_out)   MODE 2: x = silu(gu[:K]) * gu[K:]
-template <int MODE, int RPW, int UN>
+//   ROPE (RPW == 2): the wave's two rows are (head*128 + d, head*128 + d + 64), i.e. one rotary pair; rows below
+//   rope_rows (the q and k heads of a fused qkv projection) are rotated by cs[pos] before the store - the RoPE launch
+//   of the decode step disappears.  Values are rounded to bf16 before the rotation, like the separate kernel sees them.
+template <int MODE, int RPW, int UN, bool ROPE = false>
 __global__ __launch_bounds__(256) void gemv2_kernel(const uint16_t* __restrict__ W, const uint16_t* __restrict__ h,
                                                     uint16_t* __restrict__ h_out, const uint16_t* __restrict__ delta,
                                                     const uint16_t* __restrict__ nw, const uint16_t* __restrict__ gu,
-                                                    uint16_t* __restrict__ y, int N, int K, float eps) {
+                                                    uint16_t* __restrict__ y, int N, int K, float eps,
+                                                    const int64_t* __restrict__ pos = nullptr,
+                                                    const float* __restrict__ cs = nullptr, int rope_rows = 0) {
+  static_assert(!ROPE || RPW == 2, "a rotary pair per wave");
   extern __shared__ __attribute__((aligned(16))) uint16_t s_x[];  // [K]
   __shared__ float s_part[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  const int wid = blockIdx.x * 4 + wave;
+  const int row0 = ROPE ? (wid >> 6) * 128 + (wid & 63) : wid * RPW;
+  constexpr int RSTEP = ROPE ? 64 : 1;  // distance between the wave's rows
   const int nb = K / (8 * 64 * UN);  // batches; K % (512 UN) == 0 checked on the host
   const uint16_t* wrow[RPW];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) wrow[r] = W + (size_t)min(row0 + r, N - 1) * K + lane * 8;
+  for (int r = 0; r < RPW; ++r) wrow[r] = W + (size_t)min(row0 + r * RSTEP, N - 1) * K + lane * 8;
   u32x4_t cur[RPW][UN], nxt[RPW][UN];
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
@@ -356,6 +364,22 @@ __global__ __launch_bounds__(256) void gemv2_kernel(const uint16_t* __restrict__
 #pragma unroll
       for (int u = 0; u < UN; ++u) cur[r][u] = nxt[r][u];
   }
+  if (ROPE) {
+    const float a = bf2f(f2bf(wave_sum(acc[0]))), b = bf2f(f2bf(wave_sum(acc[RPW - 1])));
+    if (lane == 0 && row0 + 64 < N) {
+      if (row0 < rope_rows) {
+        const float* t = cs + (size_t)pos[0] * 128;  // [cos(64) | sin(64)]
+        const int d = row0 & 63;
+        const float c = t[d], sn = t[64 + d];
+        y[row0] = f2bf(a * c - b * sn);
+        y[row0 + 64] = f2bf(b * c + a * sn);
+      } else {
+        y[row0] = f2bf(a);
+        y[row0 + 64] = f2bf(b);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const float t = wave_sum(acc[r]);
@@ -387,6 +411,18 @@ extern "C" int shell_gemv_norm(const void* W, const void* h, void* h_out, const 
   hipLaunchKernelGGL((gemv_fused_kernel<1, 4>), dim3(blocks), dim3(256), (size_t)K * 2, (hipStream_t)stream,
                      (const uint16_t*)W, (const uint16_t*)h, (uint16_t*)h_out, (const uint16_t*)delta,
                      (const uint16_t*)nw, nullptr, (uint16_t*)y, N, K, eps);
+  return 0;
+}
+// qkv projection of one decode token with RMSNorm on the way in and RoPE on the way out (no q/k-norm models only)
+extern "C" int shell_gemv_norm_rope(const void* W, const void* h, void* h_out, const void* delta, const void* nw,
+                                    void* y, int N, int K, float eps, const void* pos, const void* cs, int rope_rows,
+                                    void* stream) {
+  if (h == h_out || !gemv2_ok(N, K) || N % 128 || rope_rows % 128) return -1;
+  const int blocks = N / (4 * G2_RPW);
+  hipLaunchKernelGGL((gemv2_kernel<1, G2_RPW, G2_UN, true>), dim3(blocks), dim3(256), (size_t)K * 2,
+                     (hipStream_t)stream, (const uint16_t*)W, (const uint16_t*)h, (uint16_t*)h_out,
+                     (const uint16_t*)delta, (const uint16_t*)nw, nullptr, (uint16_t*)y, N, K, eps,
+                     (const int64_t*)pos, (const float*)cs, rope_rows);
   return 0;
 }
 extern "C" int shell_gemv_silu(const void* W, const void* gu, void* y, int N, int K, void* stream) {
