@@ -40,6 +40,7 @@ constexpr int PF_ROWS = 256;   // query rows per workgroup
 constexpr int PF_KT = 64;      // keys per tile
 constexpr int PF_THREADS = 512;
 
+
 constexpr int PF_KSTR = 272;                      // K image row stride: 256 + 16 B pad -> conflict-free ds_read_b128
 constexpr int PF_VSTR = 320;                      // V image row stride: 256 + 64 B pad -> conflict-free ds_read_b64_tr_b16
 constexpr int PF_KTILE = PF_KT * PF_KSTR;         // 17,408 B
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   // Measured (32K tokens, bf16, TFLOP/s): this loop 1043.  Lock-step phases (QK, softmax, PV of one tile) 840; a
   // half-tile stagger of waves 4-7 with two barriers per tile 786; row sums by an all-ones MFMA instead of 32 v_add
   // 958 (+16 VGPRs spill); the row-sum adds pinned into this block, where hipcc then forms one VALU lump between the
-  // MFMA runs, 968 (sched_group_barrier pipelines did not break the lump up).
+  // MFMA runs, 968; sched_group_barrier pipelines over the whole block or over two sched_barrier-separated regions 968.
   char* const kbase = smem;
   char* const vbase = smem + 2 * PF_KTILE;
   const uint32_t kst = srow * PF_KSTR + sch * 16, vst = srow * PF_VSTR + sch * 16;

@@ -40,6 +40,9 @@ def test_prefill_golden(dev, name):
     (3, 8, 8, 128, 128, 140, [64, 65, 2]),       # G = 1
     (2, 16, 2, 64, 128, 200, [130, 70]),         # G = 8, D = 64
     (2, 8, 4, 128, 128, 260, [256, 300]),        # G = 2
+    (2, 32, 8, 128, 32, 150, [70, 200]),         # PS = 32: a 64-key tile spans two pages (per-row page lookup path)
+    (2, 16, 4, 128, 96, 300, [130, 257]),        # PS = 96: tiles straddle page boundaries at varying offsets
+    (1, 32, 8, 128, 64, 700, [300]),             # PS = 64: one tile per page (scalar page-walk path, many pages)
 ])
 def test_prefill_oracle_shapes(dev, dtype, B, HQ, HKV, D, PS, cache_max, append):
     """Per-head-varying prefix lengths, shuffled pages, batch_mapping != arange, strided v (untested
