@@ -149,6 +149,21 @@ def roofline_prefill_attn(model, ctx, rounds=3):
             "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops_per_launch": flops}
 
 
+def copy_bandwidth_gbs(dev, nbytes=1 << 30, rounds=5):
+    """Practical HBM roof next to the 8 TB/s spec: a device-to-device copy of 1 GiB (read + write =
+    2 GiB moved) timed with events on the current stream."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * rounds / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic(workload, alg_bytes):
     """HBM bytes per launch from the PMC counters.  Counters cannot be read from inside the benchmark, so this
     returns the figure of the committed rocprofv3 --pmc passes over THIS command (profiles/*_pmc.json,
@@ -208,11 +223,28 @@ def cpu_baseline(budget_s=20.0):
     t_dec = (time.perf_counter() - t1) / max(nd, 1)
     new = 16
     tok_s = (Lp + new) / (layers * (t_prefill + new * t_dec))
+    # the same prefill-attention call on ONE thread (SURVEY 8d asks for both), only if the budget allows
+    t_one = None
+    if time.perf_counter() - t0 < budget_s:
+        torch.set_num_threads(1)
+        t2 = time.perf_counter()
+        O.prefill_attention(q, k, v, kc, vc, lens0, pt, bm, cu, HKV, PS)
+        t_one = time.perf_counter() - t2
+        torch.set_num_threads(cores)
+        t3 = time.perf_counter()
+        O.prefill_attention(q, k, v, kc, vc, lens0, pt, bm, cu, HKV, PS)
+        t_all = time.perf_counter() - t3
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        cpu_model = "unknown"
     return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"CPU oracle (torch fp32, {cores} threads) of the attention path only: 1 layer timed "
                       f"(prefill attention + Compactor scoring + select/compact {t_prefill:.2f} s for {Lp} tokens; "
                       f"decode attention {t_dec * 1e3:.1f} ms/token over the 50% cache), scaled to {layers} layers "
-                      f"and {new} new tokens; HQ=32 HKV=8 D=128 bf16"}
+                      f"and {new} new tokens; HQ=32 HKV=8 D=128 bf16; host CPU {cpu_model}, {avail} cores visible"
+                      + ("" if t_one is None else f"; prefill attention alone: {t_one:.2f} s on 1 thread vs "
+                                                  f"{t_all:.2f} s on {cores}")}
 
 
 def main():
@@ -308,6 +340,9 @@ def main():
         state = {}
         step(state)  # one more generate whose cache stays allocated: the roofline leg runs on the real cache
         result["roofline"] = roofline_decode_attn(model, state, args.workload)
+        copy_bw = copy_bandwidth_gbs(dev)
+        result["roofline"]["copy_bw"] = round(copy_bw, 1)  # measured device copy rate: the practical HBM roof
+        result["roofline"]["frac_of_copy_bw"] = round(result["roofline"]["achieved"] / copy_bw, 4)
         result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
         for bi in state["rows"]:
             model.cache.free_batch(bi)

@@ -139,3 +139,41 @@ def test_prefill_deterministic_and_large_logits(dev, dtype):
     ref = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale)
     d = (out1.cpu().float() - ref.float()).abs().max()
     assert torch.allclose(out1.cpu().float(), ref.float(), rtol=1e-6, atol=tol(dtype)), d
+
+
+@pytest.mark.parametrize("split", [1024, 1000])
+def test_prefill_chunked_equals_one_shot(dev, split):
+    """SURVEY 8f-3 property: prefill in two chunks (chunk 1 written to the paged cache with prefill_store_all_kv,
+    chunk 2 attending to [cached prefix || itself]) equals the one-shot causal prefill within the attention tolerance
+    (the softmax is the same sum in a different tile order)."""
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+    from compactor_vllm_amd.kv_cache.store_kv_cache import prefill_store_all_kv
+
+    dtype, HQ, HKV, D, PS, N = torch.bfloat16, 32, 8, 128, 128, 2048
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(N, HQ, D, generator=g).to(dtype).to(dev)
+    k = torch.randn(N, HKV, D, generator=g).to(dtype).to(dev)
+    v = torch.randn(N, HKV, D, generator=g).to(dtype).to(dev)
+    P = N // PS
+    pt = torch.randperm(2 * HKV * P, generator=g).view(2, HKV, P).to(torch.int32).to(dev)
+    kc = torch.zeros(2 * HKV * P * PS, D, dtype=dtype, device=dev)
+    vc = torch.zeros_like(kc)
+    bm = torch.ones(1, dtype=torch.int32, device=dev)
+    zero = torch.zeros(1, HKV, dtype=torch.int32, device=dev)
+
+    cu = torch.tensor([0, N], dtype=torch.int32, device=dev)
+    one = causal_sparse_varlen_with_cache(q, k, v, kc, vc, zero, pt, bm, cu, N, 0, HKV, PS)
+
+    cu1 = torch.tensor([0, split], dtype=torch.int32, device=dev)
+    o1 = causal_sparse_varlen_with_cache(q[:split], k[:split], v[:split], kc, vc, zero, pt, bm, cu1, split, 0, HKV, PS)
+    lens = zero.clone()
+    prefill_store_all_kv(new_keys=k[:split], new_values=v[:split], cu_seqlens_k=cu1, max_seqlen_k=split, k_cache=kc,
+                         v_cache=vc, page_table=pt, bh_lens=lens, batch_mapping=bm, PAGE_SIZE=PS)
+    assert int(lens.min()) == split and int(lens.max()) == split
+    rest = N - split
+    cu2 = torch.tensor([0, rest], dtype=torch.int32, device=dev)
+    o2 = causal_sparse_varlen_with_cache(q[split:], k[split:], v[split:], kc, vc, lens, pt, bm, cu2, rest, split, HKV, PS)
+    torch.cuda.synchronize()
+    two = torch.cat([o1, o2])
+    d = (one.float() - two.float()).abs().max()
+    assert torch.allclose(one.float(), two.float(), rtol=1e-6, atol=tol(dtype)), d
