@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
   __shared__ float s_mean[LV_KD];
   __shared__ float s_G[LV_KD * LV_LD];    // Gram -> Cholesky factor L (lower)
   __shared__ float s_Li[LV_KD];           // 1 / L[k][k]
-  __shared__ float s_tile[64 * LV_LD];    // 64 centred rows
+  __shared__ __attribute__((aligned(16))) float s_tile[64 * LV_LD];  // 64 centred rows; later L repacked [48][48]
   const int cidx = blockIdx.x / HKV, hh = blockIdx.x % HKV;
   const int beg = chunk_cu[cidx], end = chunk_cu[cidx + 1];
   const int L = end - beg;
@@ -304,12 +304,35 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
   const int tid = threadIdx.x;
   const float* Xh = X + ((size_t)hh * N + beg) * LV_KD;
 
-  // column means: thread (col = tid % 48, slice = tid / 48) for tid < 240
+  // Two passes over the chunk in 64-row tiles (column sums, then the centred Gram).  A tile is 64 x 48 floats =
+  // 12 coalesced loads per thread; the next tile's loads are in flight while the current one is consumed from LDS
+  // (the first version's column means were 102 dependent strided global loads per thread).
+  constexpr int TPT = 64 * LV_KD / 256;  // tile elements per thread
+  float pre[TPT];
+  auto tile_load = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+      const int e = tid + 256 * j, rr = e / LV_KD;
+      pre[j] = (i0 + rr) < L ? Xh[(size_t)i0 * LV_KD + e] : 0.f;
+    }
+  };
+  // ---- pass A: column means
   {
+    const int col = tid % LV_KD, sl = tid / LV_KD;  // 5 row slices for tid < 240
     float sum = 0.f;
-    const int col = tid % LV_KD, sl = tid / LV_KD;
-    if (tid < 5 * LV_KD)
-      for (int i = sl; i < L; i += 5) sum += Xh[(size_t)i * LV_KD + col];
+    tile_load(0);
+    for (int i0 = 0; i0 < L; i0 += 64) {
+#pragma unroll
+      for (int j = 0; j < TPT; ++j) {
+        const int e = tid + 256 * j;
+        s_tile[(e / LV_KD) * LV_LD + e % LV_KD] = pre[j];
+      }
+      __syncthreads();
+      if (i0 + 64 < L) tile_load(i0 + 64);
+      if (tid < 5 * LV_KD)
+        for (int rr = sl; rr < 64; rr += 5) sum += s_tile[rr * LV_LD + col];  // rows past L are zero
+      __syncthreads();
+    }
     s_tile[tid] = (tid < 5 * LV_KD) ? sum : 0.f;
     __syncthreads();
     if (tid < LV_KD) {
@@ -319,33 +342,43 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
     }
     __syncthreads();
   }
-  // Gram: thread owns 9 entries e = tid + 256*j  (48*48 = 2304 = 9*256)
-  float gacc[9];
+  // ---- pass B: Gram.  Thread (ta, tb) owns the 3 x 3 block G[3ta.., 3tb..] (16 x 16 threads cover 48 x 48): 6 LDS
+  // reads feed 9 FMAs per row (one entry per thread index needed 18).  In a wave the a-operands are 4 broadcast groups
+  // and the b-operands 16 addresses 3 floats apart: conflict free.
+  static_assert(LV_KD == 48, "3 x 3 blocks on a 16 x 16 thread grid");
+  const int ta = tid >> 4, tb = tid & 15;
+  float gacc[3][3];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) gacc[j] = 0.f;
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gacc[i][j] = 0.f;
+  tile_load(0);
   for (int i0 = 0; i0 < L; i0 += 64) {
-    const int rows = min(64, L - i0);
-    for (int e = tid; e < 64 * LV_KD; e += 256) {
-      const int rr = e / LV_KD, cc = e % LV_KD;
-      s_tile[rr * LV_LD + cc] = rr < rows ? Xh[(size_t)(i0 + rr) * LV_KD + cc] - s_mean[cc] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+      const int e = tid + 256 * j, rr = e / LV_KD, cc = e % LV_KD;
+      s_tile[rr * LV_LD + cc] = (i0 + rr) < L ? pre[j] - s_mean[cc] : 0.f;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int e = tid + 256 * j;
-      const int a = e / LV_KD, bcol = e % LV_KD;
-      float t = gacc[j];
-      for (int rr = 0; rr < 64; ++rr) t = fmaf(s_tile[rr * LV_LD + a], s_tile[rr * LV_LD + bcol], t);
-      gacc[j] = t;
+    if (i0 + 64 < L) tile_load(i0 + 64);
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) {
+      const float* row = s_tile + rr * LV_LD;
+      const float a0 = row[3 * ta], a1 = row[3 * ta + 1], a2 = row[3 * ta + 2];
+      const float b0 = row[3 * tb], b1 = row[3 * tb + 1], b2 = row[3 * tb + 2];
+      gacc[0][0] = fmaf(a0, b0, gacc[0][0]); gacc[0][1] = fmaf(a0, b1, gacc[0][1]); gacc[0][2] = fmaf(a0, b2, gacc[0][2]);
+      gacc[1][0] = fmaf(a1, b0, gacc[1][0]); gacc[1][1] = fmaf(a1, b1, gacc[1][1]); gacc[1][2] = fmaf(a1, b2, gacc[1][2]);
+      gacc[2][0] = fmaf(a2, b0, gacc[2][0]); gacc[2][1] = fmaf(a2, b1, gacc[2][1]); gacc[2][2] = fmaf(a2, b2, gacc[2][2]);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int e = tid + 256 * j;
-    const int a = e / LV_KD, bcol = e % LV_KD;
-    s_G[a * LV_LD + bcol] = gacc[j] + (a == bcol ? reg : 0.f);
-  }
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ar = 3 * ta + i, bc = 3 * tb + j;
+      s_G[ar * LV_LD + bc] = gacc[i][j] + (ar == bc ? reg : 0.f);
+    }
   __syncthreads();
   // Cholesky G = L L^T by ONE wave, entirely in registers: lane i owns row i (48 floats, compile-time indexed by
   // full unrolling); column j of L is broadcast to the other lanes with v_readlane.  ~2.3K instructions, no barrier,
@@ -372,10 +405,16 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
     }
   }
   __syncthreads();
+  // L (strictly lower part, zero elsewhere) repacked with a 16-byte aligned leading dimension so that the forward
+  // substitution reads four entries of a row per ds_read_b128 (every thread reads the same address: broadcast)
+  float* s_L = s_tile;  // [48][48], the tile buffer is free now
+  for (int e = tid; e < LV_KD * LV_KD; e += 256) {
+    const int rr = e / LV_KD, cc = e % LV_KD;
+    s_L[e] = cc < rr ? s_G[rr * LV_LD + cc] : 0.f;
+  }
   if (tid < LV_KD) s_Li[tid] = 1.0f / s_G[tid * LV_LD + tid];  // reciprocal diagonal
   __syncthreads();
-  // score_i = || L^-1 xc_i ||^2 by forward substitution, one row per thread; L is read from LDS at compile-time
-  // offsets (every thread reads the same address: broadcast, conflict free)
+  // score_i = || L^-1 xc_i ||^2 by forward substitution, one row per thread, everything at compile-time offsets
   for (int i = tid; i < L; i += 256) {
     float y[LV_KD];
 #pragma unroll
@@ -385,7 +424,13 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
     for (int kk = 0; kk < LV_KD; ++kk) {
       float t = y[kk];
 #pragma unroll
-      for (int m = 0; m < kk; ++m) t = fmaf(-s_G[kk * LV_LD + m], y[m], t);
+      for (int m4 = 0; m4 < (kk + 3) / 4; ++m4) {  // entries m >= kk of row kk are zero: no masking needed
+        const float4 l4 = *reinterpret_cast<const float4*>(s_L + kk * LV_KD + 4 * m4);
+        t = fmaf(-l4.x, y[4 * m4], t);
+        if (4 * m4 + 1 < kk) t = fmaf(-l4.y, y[4 * m4 + 1], t);
+        if (4 * m4 + 2 < kk) t = fmaf(-l4.z, y[4 * m4 + 2], t);
+        if (4 * m4 + 3 < kk) t = fmaf(-l4.w, y[4 * m4 + 3], t);
+      }
       t *= s_Li[kk];
       y[kk] = t;
       sc = fmaf(t, t, sc);
@@ -407,6 +452,7 @@ template <typename T, int D, int G, bool PASS2>
 __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                      int64_t sq_n, int64_t sk_n, int64_t sk_h,
                                                      float* __restrict__ scores, float* __restrict__ part,
+                                                     const float* __restrict__ lse,
                                                      const int* __restrict__ cu_q, const int* __restrict__ cu_k,
                                                      int B, int HKV, int w, int ntile_max, float scale_log2e,
                                                      int pool) {
@@ -446,20 +492,10 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
     *reinterpret_cast<uint4*>(s_k + ktile_off(row, ch)) = val;
   }
   if (PASS2) {
-    // exact lse of every window row from the per-tile partials (m, s) written by pass 1
-    for (int row = tid; row < nqb * 32; row += 256) {
-      float m = -INFINITY, ssum = 0.f;
-      if (row < rows_b) {
-        for (int t = 0; t < ntile; ++t) {
-          const float* pp = part + ((((size_t)b * HKV + g) * ntile_max + t) * (SK_MAXQB * 32) + row) * 2;
-          const float mt = pp[0], st = pp[1];
-          const float mn = fmaxf(m, mt);
-          ssum = ssum * __builtin_amdgcn_exp2f(m - mn) + st * __builtin_amdgcn_exp2f(mt - mn);
-          m = mn;
-        }
-      }
-      s_lse[row] = row < rows_b ? m + __builtin_amdgcn_logf(ssum) : INFINITY;
-    }
+    // exact lse of every window row: reduced over the tiles ONCE per (b, g) by snapkv_lse_kernel (every workgroup
+    // redoing that 256-step reduction was 160 of this pass's 192 us at 32 K keys)
+    const float* lp = lse + ((size_t)b * HKV + g) * (SK_MAXQB * 32);
+    for (int row = tid; row < nqb * 32; row += 256) s_lse[row] = row < rows_b ? lp[row] : INFINITY;
   }
   __syncthreads();
 
@@ -549,6 +585,43 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
     }
     if (tile == 0)  // last w keys <- +inf (snapkv.py:267-276)
       for (int i = tid; i < w; i += 256) scores[(size_t)(kb0 + keff + i) * HKV + g] = INFINITY;
+  }
+}
+
+// lse[b, g, row] = log2-domain log-sum-exp of window row `row` over all scored keys, from the per-tile (max, sum)
+// partials of pass 1.  One workgroup per (b, g); thread = (row, slice of the tiles); slices meet in LDS.
+constexpr int SK_LSE_SLICES = 4;
+__global__ __launch_bounds__(SK_MAXQB * 32 * SK_LSE_SLICES) void snapkv_lse_kernel(
+    const float* __restrict__ part, float* __restrict__ lse, const int* __restrict__ cu_k, int HKV, int w, int G,
+    int ntile_max) {
+  constexpr int ROWS = SK_MAXQB * 32;
+  __shared__ float s_m[SK_LSE_SLICES][ROWS], s_s[SK_LSE_SLICES][ROWS];
+  const int bg = blockIdx.x, b = bg / HKV;
+  const int row = threadIdx.x % ROWS, sl = threadIdx.x / ROWS;
+  const int keff = cu_k[b + 1] - cu_k[b] - w;
+  const int ntile = keff > 0 ? (keff + SK_TILE - 1) / SK_TILE : 0;
+  const int rows_b = w * G;
+  float m = -INFINITY, ssum = 0.f;
+  if (row < rows_b) {
+    const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)bg * ntile_max * ROWS + row;
+    for (int t = sl; t < ntile; t += SK_LSE_SLICES) {
+      const float2 ms = pp[(size_t)t * ROWS];
+      const float mn = fmaxf(m, ms.x);
+      ssum = ssum * __builtin_amdgcn_exp2f(m - mn) + ms.y * __builtin_amdgcn_exp2f(ms.x - mn);
+      m = mn;
+    }
+  }
+  s_m[sl][row] = m;
+  s_s[sl][row] = ssum;
+  __syncthreads();
+  if (sl == 0 && row < rows_b) {
+    float M = s_m[0][row];
+#pragma unroll
+    for (int i = 1; i < SK_LSE_SLICES; ++i) M = fmaxf(M, s_m[i][row]);
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SK_LSE_SLICES; ++i) tot += s_s[i][row] * __builtin_amdgcn_exp2f(s_m[i][row] - M);
+    lse[(size_t)bg * ROWS + row] = M + __builtin_amdgcn_logf(tot);
   }
 }
 
@@ -684,7 +757,8 @@ extern "C" size_t cvllm_snapkv_workspace_bytes(int B, int HKV, int w, int max_se
   if (B <= 0 || HKV <= 0 || max_seqlen_k <= 0) return 0;
   (void)w;
   const size_t ntile = ((size_t)max_seqlen_k + SK_TILE - 1) / SK_TILE;
-  return (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2 * sizeof(float);
+  // per-tile (max, sum) partials of pass 1 + the reduced lse per window row
+  return (size_t)B * HKV * (ntile * 2 + 1) * (SK_MAXQB * 32) * sizeof(float);
 }
 
 template <typename T, int D>
@@ -693,12 +767,15 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
                     int pool, hipStream_t st) {
   const float c = scale * 1.4426950408889634f;
   dim3 grid(B * ntile * HKV), block(256);
+  float* lse = part + (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2;
 #define SNAP(G_)                                                                                                      \
   {                                                                                                                   \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,  \
-                       sq_n, sk_n, sk_h, scores, part, cu_q, cu_k, B, HKV, w, ntile, c, pool);                         \
+                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \
+    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV), dim3(SK_MAXQB * 32 * SK_LSE_SLICES), 0, st,                   \
+                       (const float*)part, lse, cu_k, HKV, w, G_, ntile);                                             \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
-                       sq_n, sk_n, sk_h, scores, part, cu_q, cu_k, B, HKV, w, ntile, c, pool);                         \
+                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \
   }
   switch (G) {
     case 1: SNAP(1); break;
