@@ -330,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   const int c = lane / LPR;
   const int dl = lane % LPR;
 
+  const int bt = bmap[b];  // first link of the metadata chain: issued before anything else
   // q and the new K/V row depend on (b, h) only: issued first, in flight together with the batch_mapping -> length /
   // page-table chain below instead of after it (one dependent memory round trip less in front of the first K/V byte;
   // the fixed ~6 us of this kernel is that chain).  Every split loads the new row; its owner uses it.
@@ -348,7 +349,6 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   const u32x4_t kn4 = *(gptr_t*)(uintptr_t)knp, vn4 = *(gptr_t*)(uintptr_t)vnp;
   uint4 knew = make_uint4(kn4[0], kn4[1], kn4[2], kn4[3]);
   uint4 vnew = make_uint4(vn4[0], vn4[1], vn4[2], vn4[3]);
-  const int bt = bmap[b];
   const int lidx = lens_by_row ? bt * HKV + h : bh;
   DEC_TS(1);
   const int L_old = seq_lens[lidx];  // issued before the page-id loads, consumed after them
@@ -600,10 +600,10 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
         if (S == 1) {
           out[((size_t)b * HQ + h * G + g) * D + d0 + o] = to16<T>(ov);
         } else {
-          po[g * D + d0 + o] = ov;
+          __builtin_nontemporal_store(ov, &po[g * D + d0 + o]);  // consumed once, by the merge kernel
         }
       }
-      if (S != 1 && d0 == 0) pl[g] = M + __logf(den);
+      if (S != 1 && d0 == 0) __builtin_nontemporal_store(M + __logf(den), &pl[g]);
     }
   } else {  // empty split (covers L == 0 and RESERVED rows)
     if (S == 1) {
