@@ -600,10 +600,10 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
         if (S == 1) {
           out[((size_t)b * HQ + h * G + g) * D + d0 + o] = to16<T>(ov);
         } else {
-          __builtin_nontemporal_store(ov, &po[g * D + d0 + o]);  // consumed once, by the merge kernel
+          po[g * D + d0 + o] = ov;
         }
       }
-      if (S != 1 && d0 == 0) __builtin_nontemporal_store(M + __logf(den), &pl[g]);
+      if (S != 1 && d0 == 0) pl[g] = M + __logf(den);
     }
   } else {  // empty split (covers L == 0 and RESERVED rows)
     if (S == 1) {
