@@ -108,11 +108,13 @@ def test_decode_long_context_vs_torch(dev, B, L):
             assert torch.allclose(out[b, h * G : (h + 1) * G].float(), p @ V, atol=2e-2)
 
 
-def test_prefill_32k_properties(dev):
-    """C3-size dense causal prefill: V == const -> output == const; sampled rows against the fp32 definition."""
+@pytest.mark.parametrize("N", [32768, 131072 - 256])
+def test_prefill_full_size_properties(dev, N):
+    """C3-size (32 K) and C5-size (128 K - 256, BASELINE.json configs[4]) dense causal prefill: V == const -> output ==
+    const; sampled rows against the fp32 definition."""
     from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
 
-    dtype, B, HQ, HKV, D, PS, N = torch.bfloat16, 1, 32, 8, 128, 128, 32768
+    dtype, B, HQ, HKV, D, PS = torch.bfloat16, 1, 32, 8, 128, 128
     g = torch.Generator(device=dev).manual_seed(7)
     q = torch.randn(N, HQ, D, device=dev, generator=g).to(dtype)
     k = torch.randn(N, HKV, D, device=dev, generator=g).to(dtype)
@@ -125,7 +127,7 @@ def test_prefill_32k_properties(dev):
     args = (kc, kc, lens, pt, bm, cu, N, 0, HKV, PS)
     out = causal_sparse_varlen_with_cache(q, k, v, *args)
     G = HQ // HKV
-    for t in (0, 63, 64, 8191, 20000, 32767):
+    for t in (0, 63, 64, 8191, 20000, N - 1):
         for hq in (0, 13, 31):
             kk = k[: t + 1, hq // G].float()
             p = torch.softmax(q[t, hq].float() @ kk.T / math.sqrt(D), -1)
