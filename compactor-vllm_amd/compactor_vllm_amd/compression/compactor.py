@@ -37,9 +37,9 @@ class CompactorCompression(BaseCompressionMethod):
     def post_rope_scoring(q, k, v, pre_rope_scores: torch.Tensor, context) -> Optional[torch.Tensor]:
         cc = context.compression_context
         # The reference runs this on the main stream while `pre_rope_scores` is still being produced on
-        # STORE_STREAM with no dependency edge (hazard H1).  Here the edge is explicit.
-        if context.STORE_STREAM is not None and pre_rope_scores is not None:
-            torch.cuda.current_stream().wait_stream(context.STORE_STREAM)
+        # STORE_STREAM with no dependency edge (hazard H1).  Here it runs on STORE_STREAM like every
+        # other piece of the scoring -> select -> compaction chain: in order behind the pre-RoPE scores (no hazard,
+        # no wait on the main stream) and under the prefill attention instead of in front of it.
         return maybe_execute_in_stream(
             non_causal_attn_scores,
             q,
@@ -55,6 +55,7 @@ class CompactorCompression(BaseCompressionMethod):
             protected_first_tokens=cc.protected_first_tokens,
             protected_last_tokens=cc.protected_last_tokens,
             accum_blending=0.5,
+            STORE_STREAM=context.STORE_STREAM,
         )
 
 
