@@ -256,8 +256,10 @@ def main():
     ap.add_argument("--ctx", type=int, default=0)
     ap.add_argument("--new", type=int, default=0)
     ap.add_argument("--ratio", type=float, default=-1.0)
+    ap.add_argument("--seqs", type=int, default=1, help="sequences per GPU (the metric's configs use 1)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-multi-seq", action="store_true", help="skip the extra 4-sequences-per-GPU leg (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,12 +289,17 @@ def main():
     ratio = args.ratio if args.ratio >= 0 else ratio
     method = CompressionMethod[method_name]
     cfg = {"llama": bs.LLAMA31_8B, "qwen3": bs.QWEN3_8B, "tiny": bs.TINY}[shape]
-    model = bs.ModelShell(cfg, dev, max_model_len=ctx + new, max_seqs=1, seed=0)
+    nseq = max(1, args.seqs)
+    # N = 1 only: an extra, untimed-for-`value` leg repeats the workload with MULTI sequences per GPU (what a serving
+    # batch looks like); the KV pool is sized for it up front, which does not change the 1-sequence timings
+    MULTI = 4
+    multi_leg = world == 1 and nseq == 1 and not args.no_multi_seq and args.workload != "tiny"
+    model = bs.ModelShell(cfg, dev, max_model_len=ctx + new, max_seqs=MULTI if multi_leg else nseq, seed=0)
     g = torch.Generator().manual_seed(1 + rank)
-    prompt = torch.randint(0, cfg.vocab, (ctx,), generator=g)
+    prompts = [torch.randint(0, cfg.vocab, (ctx,), generator=g) for _ in range(nseq)]
 
     def step(keep=None):
-        return model.generate([prompt], new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
+        return model.generate(prompts, new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
 
     for _ in range(args.warmup):
         step()
@@ -313,7 +320,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    tokens_per_rank = args.steps * (ctx + new)
+    tokens_per_rank = args.steps * nseq * (ctx + new)
     value = world * tokens_per_rank / elapsed
     result = {
         "metric": "prefill+decode tokens/sec @ 32K ctx, 50% KV retention, 1xMI355X; decode-attn HBM GB/s",
@@ -330,9 +337,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {cfg.name} random weights, {ctx}-token prefill + {new} decode per sequence, "
-                        f"{method_name} ratio {ratio} (protected 16/64, chunk 512), 1 sequence per GPU, "
+                        f"{method_name} ratio {ratio} (protected 16/64, chunk 512), {nseq} sequence(s) per GPU, "
                         f"store-stream overlapped scoring+eviction, HIP-graph decode",
-            "ctx": ctx, "new_tokens": new, "method": method_name, "ratio": ratio, "sequences_per_gpu": 1,
+            "ctx": ctx, "new_tokens": new, "method": method_name, "ratio": ratio, "sequences_per_gpu": nseq,
             "parallelism": f"replicas x{world} (sequences sharded, no collectives)",
         },
     }
@@ -346,6 +353,32 @@ def main():
         result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
         for bi in state["rows"]:
             model.cache.free_batch(bi)
+        if multi_leg:
+            mp = prompts + [torch.randint(0, cfg.vocab, (ctx,), generator=g) for _ in range(MULTI - 1)]
+
+            def mstep(keep=None):
+                return model.generate(mp, new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
+
+            torch.cuda.empty_cache()  # the 1-sequence legs leave the caching allocator fragmented for 4x tensors
+            mstep()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            mstate = {}
+            mstep(mstate)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            mr = roofline_decode_attn(model, mstate, "-")
+            for bi in mstate["rows"]:
+                model.cache.free_batch(bi)
+            result["multi_sequence"] = {
+                "sequences_per_gpu": MULTI, "value": round(MULTI * (ctx + new) / dt, 1), "unit": "tokens/s",
+                "ms_per_step": round(dt * 1e3, 2), "steps": 1,
+                "roofline": {k: mr[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                "avg_launch_us", "algorithmic_bytes_per_launch")},
+                "note": "same workload with 4 sequences per GPU (packed varlen prefill, batched decode): not the "
+                        "metric's configuration, shown because the decode-attention launch is then 273 MB instead "
+                        "of 68 MB",
+            }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

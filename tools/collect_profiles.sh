@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 mkdir -p "$O"
 # 1. kernel trace + the tool's own stats of the bench command
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > "$O/bench_under_rocprof.log" 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq > "$O/bench_under_rocprof.log" 2>&1
 python3 tools/prof_summary.py "$O/kt" > "$O/${R}_bench_c3_kernel_summary.txt"
 cp "$(find "$O/kt" -name '*kernel_stats.csv' | head -1)" "$O/${R}_bench_c3_kernel_stats.csv"
 grep "^{\"metric\"" "$O/bench_under_rocprof.log" | tail -1 > "$O/${R}_bench_c3_under_rocprof.json"
