@@ -206,7 +206,8 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
   // Measured (32K tokens, bf16, TFLOP/s): this loop 1043.  Lock-step phases (QK, softmax, PV of one tile) 840; a
   // half-tile stagger of waves 4-7 with two barriers per tile 786; row sums by an all-ones MFMA instead of 32 v_add
   // 958 (+16 VGPRs spill); the row-sum adds pinned into this block, where hipcc then forms one VALU lump between the
-  // MFMA runs, 968; sched_group_barrier pipelines over the whole block or over two sched_barrier-separated regions 968.
+  // MFMA runs, 968; sched_group_barrier pipelines over the whole block or over two sched_barrier-separated regions 968;
+  // a static s_setprio 1 for waves 4-7: no difference (1040 +- 2 in an A/B on one box).
   char* const kbase = smem;
   char* const vbase = smem + 2 * PF_KTILE;
   const uint32_t kst = srow * PF_KSTR + sch * 16, vst = srow * PF_VSTR + sch * 16;
