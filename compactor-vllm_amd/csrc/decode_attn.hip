@@ -4,15 +4,16 @@
 // (_varkv_stage2_reduce).  HBM-bandwidth bound: every K and V row of every (batch, kv-head) is read
 // exactly once; the G query heads of the kv-head share the rows.
 //
-// Mapping (wave64):
+// Two kernels live here.  decode_fused_kernel (below, the default for D <= 128) streams K/V through per-wave LDS rings
+// filled by LDS-DMA and can append the new token's row on the way; decode_stage1_kernel (first in the file) is the
+// register double-buffered version kept for D = 256.  Common mapping (wave64):
 //   * one workgroup (4 waves) per (b, kv-head, split); the split is a contiguous range of logical rows.
-//   * a lane loads 16 B (8 x 16-bit) of a row, so D/8 lanes cover a row and one global_load_dwordx4
-//     wave-instruction covers 64/(D/8) consecutive rows = 1 KiB contiguous inside a page: fully coalesced.
-//   * a "unit" = 4 such loads of K + 4 of V per lane (8 KiB per wave); units are double-buffered in
-//     registers so the next unit's 8 loads are in flight while the current one is reduced.
+//   * a lane loads 16 B (8 x 16-bit) of a row, so D/8 lanes cover a row and one wave-instruction covers
+//     64/(D/8) consecutive rows = 1 KiB contiguous inside a page: fully coalesced.
+//   * a "unit" = 4 such loads of K + 4 of V per lane (8 KiB per wave).
 //   * q.k by v_dot2c_f32_{f16,bf16} on the lane's 8 dims, DPP all-reduce over the D/8 lanes of the row.
-//   * every lane group keeps its own online-softmax state (m, l, acc[G][8]); groups are merged once at
-//     the end (shuffles), waves through LDS, splits by the stage-2 kernel with the LSE rule.
+//   * every lane group keeps its own online-softmax state (m, l, acc[G][8]); the states of a split are merged once
+//     at the end through LDS, splits by the stage-2 kernel with the LSE rule.
 // No MFMA: M = G <= 8 rows would waste the tile and the kernel is bandwidth bound.
 #include "common.h"
 

@@ -6,13 +6,17 @@
 //   * a workgroup owns one (sequence b, kv-head g, query tile): 256 rows = (256/G tokens) x G query heads, so
 //     every K/V tile staged in LDS is shared by all G heads of the group (the reference's M = BLOCK_M*G packing);
 //     a wave owns 32 rows and keeps their Q fragments in registers (B operand of the swapped product).
-//   * K/V are consumed in 64-key tiles, double-buffered in LDS (2 x (16 + 16) KiB), staged through registers:
-//     the global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them.
+//   * K/V are consumed in 64-key tiles staged through registers into LDS: K double-, V triple-buffered (96 KB), so
+//     that tile t+2 (global loads issued at the top of iteration t) is written at the end of iteration t behind ONE
+//     barrier per tile.
 //   * S^T = K Q^T with v_mfma_f32_32x32x16 (keys on the accumulator ROW, the query on the lane): the row softmax
 //     of a query is in-lane (+ one exchange with lane^32), and the fp32 accumulator registers 8s..8s+7 converted
 //     to 16-bit ARE the B operand of the next product O^T += V^T P^T (no LDS round trip for P).
+//   * In-wave software pipeline: iteration t issues the MFMAs of S(t+1) next to the exp / pack work of tile t, then
+//     the MFMAs of O += P(t) V(t) next to the row max of tile t+1 (see the main loop).
 //   * V^T fragments come from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose); the K tile is
-//     read row-wise with ds_read_b128.  Both images use 256-byte rows with XOR-swizzled 16-byte chunks.
+//     read row-wise with ds_read_b128.  Both images are PADDED (K rows 272 B, V rows 320 B): conflict free for
+//     their read instruction and every fragment address = one lane-constant VGPR + an immediate.
 //   * online softmax in the exp2 domain (scale*log2e folded into one FMA per logit), masked logits = -inf,
 //     P rounded to the model dtype before PV like the reference (:398), fp32 accumulate, one divide at the end.
 //   * O^T goes through LDS so that the global store is whole 256-byte rows.
