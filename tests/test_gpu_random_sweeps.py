@@ -1,0 +1,129 @@
+"""GPU parity sweeps over seeded random shapes (through the C ABI) against the CPU oracle: decode attention (plain
+and with the fused append), decode store, prefill attention.  The fixed-shape tests pin the reference's own matrices
+and the golden vectors; these walk the corners in between (page sizes 32..256, G 1..8, D 64/128, lengths around page
+and split boundaries, empty heads, shuffled pages, batch_mapping != arange)."""
+import math
+import random
+
+import pytest
+import torch
+
+from helpers import mk_paged, tol
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(seed):
+    r = random.Random(seed)
+    HKV = r.choice([1, 2, 4, 8])
+    G = r.choice([1, 2, 4, 8])
+    D = r.choice([64, 128])
+    PS = r.choice([32, 64, 128, 256])
+    B = r.choice([1, 2, 3, 5])
+    dtype = r.choice([torch.float16, torch.bfloat16])
+    return r, B, HKV * G, HKV, D, PS, dtype
+
+
+def _lens(r, B, HKV, PS, maxlen):
+    """lengths that sit on / next to page and split boundaries, plus zeros"""
+    special = [0, 1, PS - 1, PS, PS + 1, 2 * PS, 16, 63, 64, 65, 255, 256, 257, maxlen]
+    out = torch.zeros(B, HKV, dtype=torch.int32)
+    for b in range(B):
+        for h in range(HKV):
+            out[b, h] = min(maxlen, r.choice(special) if r.random() < 0.5 else r.randint(0, maxlen))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_decode_random(dev, seed):
+    from compactor_vllm_amd.attention.sparse_decode_kernel import head_sparse_decode_attention
+
+    r, B, HQ, HKV, D, PS, dtype = _cfg(1000 + seed)
+    maxlen = r.choice([40, 300, 1500, 4000])
+    lens = _lens(r, B, HKV, PS, maxlen)
+    lens[-1, -1] = maxlen
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, HQ, D, generator=g).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    ks = r.choice([None, 1, 2, 5])
+    out = head_sparse_decode_attention(q.to(dev), kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), HKV,
+                                       PS, scale, key_split=ks)
+    torch.cuda.synchronize()
+    ref = O.decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, scale)
+    d = (out.cpu().float() - ref.float()).abs().max()
+    assert torch.allclose(out.cpu().float(), ref.float(), rtol=1e-6, atol=tol(dtype)), (seed, d)
+    G = HQ // HKV
+    for b in range(B):
+        for h in range(HKV):
+            if int(lens[b, h]) == 0:
+                assert (out[b, h * G : (h + 1) * G].cpu().float() == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fused_decode_random(dev, seed):
+    """fused append + attention == oracle store + oracle attention; cache rows and the length table bit-exact."""
+    from compactor_vllm_amd.attention.sparse_decode_kernel import fused_decode_step
+
+    r, B, HQ, HKV, D, PS, dtype = _cfg(2000 + seed)
+    maxlen = r.choice([40, 300, 1500])
+    lens = _lens(r, B, HKV, PS, maxlen)
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens + 1, dtype, seed=seed, bmax_extra=2)
+    if B > 1 and r.random() < 0.5:
+        bm[r.randrange(B)] = 0  # RESERVED padding row
+    table = torch.zeros(pt.shape[0], HKV, dtype=torch.int32)
+    for b in range(B):
+        if int(bm[b]) != 0:
+            table[int(bm[b])] = lens[b]
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, HQ, D, generator=g).to(dtype)
+    k1 = torch.randn(B, HKV, D, generator=g).to(dtype)
+    v1 = torch.randn(B, HKV, D, generator=g).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    # oracle: store then attend on the gathered lengths
+    kc_o, vc_o = kc.clone(), vc.clone()
+    sl = table.index_select(0, bm.long()).contiguous()
+    O.decode_store_kv(k1, v1, bm, sl, pt, kc_o, vc_o, PS)
+    ref = O.decode_attention(q, kc_o, vc_o, sl, pt, bm, HKV, PS, scale)
+    tab_o = table.clone()
+    keep = bm != 0
+    tab_o.index_copy_(0, bm[keep].long(), sl[keep])
+    # device
+    kc_d, vc_d, tab_d = kc.to(dev), vc.to(dev), table.to(dev)
+    out = fused_decode_step(q.to(dev), k1.to(dev), v1.to(dev), kc_d, vc_d, tab_d, pt.to(dev), bm.to(dev), HKV, PS,
+                            scale)
+    torch.cuda.synchronize()
+    assert torch.equal(tab_d.cpu(), tab_o), seed
+    assert torch.equal(kc_d.cpu(), kc_o) and torch.equal(vc_d.cpu(), vc_o), seed
+    d = (out.cpu().float()[keep] - ref.float()[keep]).abs().max()
+    assert torch.allclose(out.cpu().float()[keep], ref.float()[keep], rtol=1e-6, atol=tol(dtype)), (seed, d)
+    assert (out.cpu()[~keep] == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_prefill_random(dev, seed):
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    r, B, HQ, HKV, D, PS, dtype = _cfg(3000 + seed)
+    cache_max = r.choice([0, 0, 70, 300, 900])
+    lens = _lens(r, B, HKV, PS, cache_max) if cache_max else torch.zeros(B, HKV, dtype=torch.int32)
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=seed)
+    append = [r.choice([1, 2, 31, 64, 65, 127, 200, 513]) for _ in range(B)]
+    cu = torch.tensor([0] + torch.tensor(append).cumsum(0).tolist(), dtype=torch.int32)
+    N = int(cu[-1])
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(N, HQ, D, generator=g).to(dtype)
+    qkv = torch.randn(N, (HQ + 2 * HKV) * D, generator=g).to(dtype)  # k, v: strided views of a fused projection
+    k = qkv[:, HQ * D : (HQ + HKV) * D].view(N, HKV, D)
+    v = qkv[:, (HQ + HKV) * D :].view(N, HKV, D)
+    scale = 1.0 / math.sqrt(D)
+    qkv_d = qkv.to(dev)
+    out = causal_sparse_varlen_with_cache(
+        q.to(dev), qkv_d[:, HQ * D : (HQ + HKV) * D].view(N, HKV, D), qkv_d[:, (HQ + HKV) * D :].view(N, HKV, D),
+        kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), cu.to(dev), max(append), int(lens.max()), HKV, PS,
+        scale)
+    torch.cuda.synchronize()
+    ref = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale)
+    d = (out.cpu().float() - ref.float()).abs().max()
+    assert torch.allclose(out.cpu().float(), ref.float(), rtol=1e-6, atol=tol(dtype)), (seed, d)
