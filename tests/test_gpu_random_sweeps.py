@@ -127,3 +127,52 @@ def test_prefill_random(dev, seed):
     ref = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale)
     d = (out.cpu().float() - ref.float()).abs().max()
     assert torch.allclose(out.cpu().float(), ref.float(), rtol=1e-6, atol=tol(dtype)), (seed, d)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_select_random(dev, seed):
+    """Joint top-k + page padding: kept sets and new lengths bit-exact against the oracle's canonical rule (score desc,
+    flat index asc) on adversarial score tensors: heavy ties, +-inf blocks, -0.0 vs +0.0, denormals, huge / tiny
+    magnitudes, retain from 1 to everything, PAD on and off, page sizes 32..256, non-zero starting lengths."""
+    from compactor_vllm_amd.compression.common import select_retained
+    from helpers import kept_sets_from_lists
+
+    r = random.Random(4000 + seed)
+    B = r.choice([1, 2, 3, 4])
+    H = r.choice([1, 2, 3, 4, 6, 8])
+    PS = r.choice([32, 64, 128, 256])
+    pad = r.random() < 0.7
+    lens = [r.choice([1, 5, 63, 64, 65, 129, 300, 777, 2049]) for _ in range(B)]
+    g = torch.Generator().manual_seed(seed)
+    cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+    N = int(cu[-1])
+    kind = r.choice(["normal", "quantised", "tiny", "huge", "zeros"])
+    sc = torch.randn(N, H, generator=g)
+    if kind == "quantised":
+        sc = (sc * 2).round() / 2
+    elif kind == "tiny":
+        sc = sc * 1e-41  # denormals
+    elif kind == "huge":
+        sc = sc * 1e30
+    elif kind == "zeros":
+        sc = torch.where(torch.rand(N, H, generator=g) < 0.5, torch.zeros(()), -torch.zeros(()))  # +0.0 / -0.0 ties
+    for b in range(B):
+        s, L = int(cu[b]), lens[b]
+        if r.random() < 0.6:
+            sc[s : s + min(16, L)] = float("inf")
+            sc[s + max(L - 64, 0) : s + L] = float("inf")
+        if r.random() < 0.3 and L > 3:
+            sc[s + r.randrange(L), r.randrange(H)] = float("-inf")
+    retain = torch.tensor([r.choice([1, max(1, L * H // 3), max(1, L * H - 1), L * H]) for L in lens], dtype=torch.int32)
+    lens0 = torch.randint(0, 3, (B, H), generator=g, dtype=torch.int32) * r.choice([0, 5, PS])
+    bm = torch.arange(1, B + 1, dtype=torch.int32)
+    if B >= 3 and r.random() < 0.5:
+        bm[1] = 0  # RESERVED_BATCH: keeps nothing
+    kept_o, lens_o = O.retained_sets(sc, cu, retain, lens0, bm, PS, pad)
+    kept, new_lens = select_retained(sc.to(dev), cu.to(dev), max(lens), retain.to(dev), bm.to(dev), lens0.to(dev), PS,
+                                     pad)
+    torch.cuda.synchronize()
+    assert torch.equal(new_lens.cpu(), lens_o), (seed, kind)
+    sets = kept_sets_from_lists(kept.cpu(), new_lens.cpu(), lens0)
+    ref = [sorted(kept_o[b][h]) for b in range(B) for h in range(H)]
+    assert sets == ref, (seed, kind)
