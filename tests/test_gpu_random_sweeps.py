@@ -176,3 +176,107 @@ def test_select_random(dev, seed):
     sets = kept_sets_from_lists(kept.cpu(), new_lens.cpu(), lens0)
     ref = [sorted(kept_o[b][h]) for b in range(B) for h in range(H)]
     assert sets == ref, (seed, kind)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_select_and_compaction_random(dev, seed):
+    """extract_and_store_top_kv end to end: lengths, kept sets and the cache rows written (token-ordered, bit-exact,
+    nothing outside the new rows touched) against the oracle, on shuffled pages with non-zero starting lengths."""
+    from compactor_vllm_amd.compression.common import extract_and_store_top_kv
+    from helpers import kept_sets_from_lists
+
+    r = random.Random(5000 + seed)
+    B = r.choice([1, 2, 3])
+    H = r.choice([1, 2, 4, 8])
+    D = r.choice([64, 128])
+    PS = r.choice([32, 128, 256])
+    dtype = r.choice([torch.float16, torch.bfloat16])
+    lens = [r.choice([10, 70, 129, 300, 517, 1200]) for _ in range(B)]
+    g = torch.Generator().manual_seed(seed)
+    cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+    N = int(cu[-1])
+    sc = torch.randn(N, H, generator=g)
+    if r.random() < 0.5:
+        sc = (sc * 4).round() / 4
+    for b in range(B):
+        s, L = int(cu[b]), lens[b]
+        sc[s : s + min(16, L)] = float("inf")
+        sc[s + max(L - 64, 0) : s + L] = float("inf")
+    ratio = r.choice([0.1, 0.25, 0.5, 0.9])
+    retain = torch.tensor([O.retain_count(ratio, L, 16, 64, H) for L in lens], dtype=torch.int32)
+    lens0 = torch.randint(0, 2, (B, H), generator=g, dtype=torch.int32) * r.choice([0, 7, PS])
+    total = lens0 + torch.tensor(lens, dtype=torch.int32)[:, None]
+    kc, vc, pt, bm, P = mk_paged(B, H, D, PS, total, dtype, seed=seed)
+    keys = torch.randn(N, H, D, generator=g).to(dtype)
+    vals = torch.randn(N, H, D, generator=g).to(dtype)
+    kept_o, lens_o = O.retained_sets(sc, cu, retain, lens0, bm, PS, True)
+    kcd, vcd, ld = kc.to(dev), vc.to(dev), lens0.to(dev)
+    kept, new_lens = extract_and_store_top_kv(sc.to(dev), cu.to(dev), max(lens), max(lens) * H, H, keys.to(dev),
+                                              vals.to(dev), retain.to(dev), pt.to(dev), bm.to(dev), ld, kcd, vcd, PS)
+    torch.cuda.synchronize()
+    assert torch.equal(new_lens.cpu(), lens_o) and torch.equal(ld.cpu(), lens_o), seed
+    sets = kept_sets_from_lists(kept.cpu(), new_lens.cpu(), lens0)
+    assert sets == [sorted(kept_o[b][h]) for b in range(B) for h in range(H)], seed
+    kcc, vcc = kcd.cpu(), vcd.cpu()
+    touched = torch.zeros(kc.shape[0], dtype=torch.bool)
+    i = 0
+    for b in range(B):
+        for h in range(H):
+            L0, L1 = int(lens0[b, h]), int(lens_o[b, h])
+            rows = O.cache_rows(pt[int(bm[b]), h], L1, PS)[L0:]
+            src = [int(cu[b]) + t for t in sets[i]]
+            i += 1
+            assert torch.equal(kcc[rows], keys[src, h]) and torch.equal(vcc[rows], vals[src, h]), (seed, b, h)
+            touched[rows] = True
+    assert torch.equal(kcc[~touched], kc[~touched]) and torch.equal(vcc[~touched], vc[~touched]), seed
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_scoring_random(dev, seed):
+    """Leverage (raw fp32, before the 16-bit rounding), chunk attention mass and SnapKV scores against the fp32 oracle on
+    random batches: ragged lengths incl. sub-chunk / sub-window sequences, G 1..8, D 64 / 128."""
+    from compactor_vllm_amd import _lib
+    from compactor_vllm_amd.compression.compactor import _cu_from_lens, non_causal_attn_scores, split_into_chunks
+    from compactor_vllm_amd.compression.snapkv import query_aware_key_scores
+
+    r = random.Random(6000 + seed)
+    B = r.choice([1, 2, 3])
+    HKV = r.choice([1, 2, 4, 8])
+    G = r.choice([1, 2, 4, 8])
+    D = r.choice([64, 128])
+    HQ = HKV * G
+    lens = [r.choice([20, 33, 49, 127, 128, 129, 511, 513, 700, 1300]) for _ in range(B)]
+    N = sum(lens)
+    g = torch.Generator().manual_seed(seed)
+    cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+    q = (torch.randn(N, HQ, D, generator=g) * 0.5).to(torch.bfloat16)
+    k = (torch.randn(N, HKV, D, generator=g) * 0.5).to(torch.bfloat16)
+    v = torch.zeros_like(k)
+    # a7: chunk attention mass (sm_scale = 1.0 as the reference passes, SURVEY Q3)
+    mass = non_causal_attn_scores(q.to(dev), k.to(dev), v.to(dev), cu.to(dev), max(lens), chunk_size=128, sm_scale=1.0,
+                                  normalize=False).cpu()
+    ref = O.chunk_attn_mass(q, k, cu, 128, 1.0)
+    assert torch.allclose(mass, ref, rtol=2e-4, atol=2e-4), (seed, (mass - ref).abs().max())
+    # a8: SnapKV (w = 32 only when w * G <= 256 rows)
+    if 32 * G <= 256:
+        out = query_aware_key_scores(q.to(dev), k.to(dev), cu.to(dev), cu.to(dev), w=32, max_seqlen_k=max(lens)).cpu()
+        refs = O.snapkv_scores(q, k, cu, cu, 32)
+        fin = torch.isfinite(refs)
+        assert torch.equal(torch.isfinite(out), fin), seed
+        assert torch.allclose(out[fin], refs[fin], rtol=2e-4, atol=2e-5), (seed, (out[fin] - refs[fin]).abs().max())
+    # a5: leverage scores, fp32 out of the kernel
+    if D == 128:
+        PHI = (torch.randn(D, 48, generator=g) / math.sqrt(48)).to(torch.bfloat16)
+        _, chunks = split_into_chunks(lens, 512)
+        cuc = _cu_from_lens(chunks, dev)
+        kd, pd = k.to(dev), PHI.to(dev)
+        scores = torch.empty(N, HKV, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        nb = L.cvllm_leverage_workspace_bytes(N, HKV, 48)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        st = L.cvllm_leverage_scores(kd.data_ptr(), kd.stride(0), kd.stride(1), pd.data_ptr(), scores.data_ptr(),
+                                     cuc.data_ptr(), len(chunks), N, HKV, D, 48, 5e-3, 1, ws.data_ptr(), nb,
+                                     torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        refl = O.leverage_scores(k, lens, PHI, normalize=False, chunk_size=512, out_dtype=torch.float32)
+        assert torch.allclose(scores.cpu(), refl, rtol=1e-3, atol=2e-4), (seed, (scores.cpu() - refl).abs().max())
