@@ -271,6 +271,13 @@ def main():
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    # One rank per GPU.  Rehearsal on a box with fewer GPUs than ranks (CVLLM_DIST_BACKEND=gloo): ranks wrap around the
+    # visible devices and the two scalar collectives run on the host - RCCL refuses two ranks on one device.
+    backend = os.environ.get("CVLLM_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        raise SystemExit(f"{world} ranks but {ndev} visible GPU(s)")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -278,7 +285,10 @@ def main():
         import torch.distributed as dist  # RCCL; used only for the timing barrier / max-reduce
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bench_shell as bs
     from compactor_vllm_amd.compression import CompressionMethod
@@ -305,9 +315,10 @@ def main():
         step()
 
     def fence():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
@@ -316,7 +327,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
