@@ -35,6 +35,9 @@ WORKLOADS = {
     "C2": ("llama", 16384, 256, "NONE", 1.0),        # configs[1]
     "C4": ("qwen3", 32768, 256, "SNAPKV", 0.25),     # configs[3]
     "tiny": ("tiny", 2048, 16, "COMPACTOR", 0.5),
+    # BASELINE.json configs[4], ONE GPU's share: 8 sequences of 128K context (130816 + 256 tokens; the sequences are
+    # prefilled one after the other, then decoded as a batch).  ~1 minute per step: not part of the default run.
+    "C5": ("llama", 131072 - 256, 256, "COMPACTOR", 0.5),
 }
 
 
@@ -299,7 +302,7 @@ def main():
     ratio = args.ratio if args.ratio >= 0 else ratio
     method = CompressionMethod[method_name]
     cfg = {"llama": bs.LLAMA31_8B, "qwen3": bs.QWEN3_8B, "tiny": bs.TINY}[shape]
-    nseq = max(1, args.seqs)
+    nseq = max(1, args.seqs) if args.workload != "C5" or args.seqs > 1 else 8
     # N = 1 only: an extra, untimed-for-`value` leg repeats the workload with MULTI sequences per GPU (what a serving
     # batch looks like); the KV pool is sized for it up front, which does not change the 1-sequence timings
     MULTI = 4

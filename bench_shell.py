@@ -253,7 +253,8 @@ class ModelShell:
 
     # ---- generate: prefill (+ compression overlapped on the store stream) then HIP-graph decode ----------------
     def generate(self, prompts: list, max_new_tokens: int, method: CompressionMethod, ratio: float,
-                 first: int = 16, last: int = 64, chunk: int = 512, use_graph: bool = True, keep_state=None):
+                 first: int = 16, last: int = 64, chunk: int = 512, use_graph: bool = True, keep_state=None,
+                 max_prefill_tokens: int = 262144):
         dev, cfg = self.dev, self.cfg
         B = len(prompts)
         lens = [int(p.numel()) for p in prompts]
@@ -276,11 +277,34 @@ class ModelShell:
                 batch_tokens_to_retain=torch.tensor(retain, dtype=torch.int32, device=dev),
                 max_tokens_to_retain=max(lens) * cfg.kv_heads, context_lens=lens, PHI=self.PHI,
                 protected_first_tokens=[first] * B, protected_last_tokens=[last] * B)
-        set_context(is_prefill=True, do_compression=do_comp, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=max(lens),
-                    max_seqlen_k=max(lens), batch_mapping=bm, max_bh_len=0, compression_context=cc,
-                    STORE_STREAM=self.store_stream)
-        last_rows = (cu[1:] - 1).to(torch.int64)
-        tok = self.forward(tokens, positions, last_rows)
+        if sum(lens) <= max_prefill_tokens or B == 1:
+            set_context(is_prefill=True, do_compression=do_comp, cu_seqlens_q=cu, cu_seqlens_k=cu,
+                        max_seqlen_q=max(lens), max_seqlen_k=max(lens), batch_mapping=bm, max_bh_len=0,
+                        compression_context=cc, STORE_STREAM=self.store_stream)
+            last_rows = (cu[1:] - 1).to(torch.int64)
+            tok = self.forward(tokens, positions, last_rows)
+        else:
+            # token budget of one prefill launch exceeded (the reference scheduler's max_batched_tokens,
+            # scheduler.py:65-108): prefill the sequences one after the other, then decode them as one batch
+            toks = []
+            for b in range(B):
+                L = lens[b]
+                cub = torch.tensor([0, L], dtype=torch.int32, device=dev)
+                ccb = None
+                if do_comp:
+                    ccb = CompressionContext(
+                        compression_method=method,
+                        compression_chunk_size=chunk if method == CompressionMethod.COMPACTOR else -1,
+                        batch_tokens_to_retain=cc.batch_tokens_to_retain[b : b + 1].contiguous(),
+                        max_tokens_to_retain=L * cfg.kv_heads, context_lens=[L], PHI=self.PHI,
+                        protected_first_tokens=[first], protected_last_tokens=[last])
+                set_context(is_prefill=True, do_compression=do_comp, cu_seqlens_q=cub, cu_seqlens_k=cub, max_seqlen_q=L,
+                            max_seqlen_k=L, batch_mapping=bm[b : b + 1].contiguous(), max_bh_len=0,
+                            compression_context=ccb, STORE_STREAM=self.store_stream)
+                s0 = int(cu[b])
+                toks.append(self.forward(tokens[s0 : s0 + L], positions[s0 : s0 + L],
+                                         torch.tensor([L - 1], dtype=torch.int64, device=dev)))
+            tok = torch.cat(toks)
         # H2 of SURVEY §3.1: lengths are written on the store stream; join before anything reads them
         torch.cuda.current_stream().wait_stream(self.store_stream)
         if do_comp:

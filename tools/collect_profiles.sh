@@ -39,5 +39,10 @@ grep "^{\"metric\"" "$O/bench_c2.log" | tail -1 > "$O/${R}_bench_c2.json"
 python3 bench.py --workload C4 --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench_c4.log" 2>&1
 grep "^{\"metric\"" "$O/bench_c4.log" | tail -1 > "$O/${R}_bench_c4.json"
 echo "[6/6] bench lines done"
+# 7. optional (COLLECT_C5=1, ~3 min): one GPU's share of BASELINE.json configs[4] - 8 sequences of 128K context
+if [ "${COLLECT_C5:-0}" = "1" ]; then
+  python3 bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline > "$O/bench_c5.log" 2>&1
+  grep "^{\"metric\"" "$O/bench_c5.log" | tail -1 > "$O/${R}_bench_c5_per_gpu.json"
+fi
 rm -f "$O"/*.log
 ls -la "$O"

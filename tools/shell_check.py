@@ -26,4 +26,16 @@ for cfg in (bs.TINY, MID):
     print("common prefix", first_diff)
     assert first_diff >= 8, "fused and unfused decode paths diverge early"
     del m
+# packed varlen prefill of 3 sequences == one-by-one prefill followed by the same batched decode
+m = bs.ModelShell(MID, dev, max_model_len=900, max_seqs=3, seed=0)
+g = torch.Generator().manual_seed(2)
+prompts = [torch.randint(0, MID.vocab, (n,), generator=g) for n in (700, 333, 512)]
+a = m.generate(prompts, 12, CompressionMethod.COMPACTOR, 0.5).cpu()
+b = m.generate(prompts, 12, CompressionMethod.COMPACTOR, 0.5, max_prefill_tokens=1).cpu()
+print("packed    :", a[:, :6].tolist())
+print("sequential:", b[:, :6].tolist())
+assert torch.equal(a[:, 0], b[:, 0]), "first tokens differ between packed and one-by-one prefill"
+pref = min(next((i for i in range(a.shape[1]) if a[r, i] != b[r, i]), a.shape[1]) for r in range(3))
+print("common prefix", pref)
+assert pref >= 6
 print("shell check ok")
