@@ -280,3 +280,39 @@ def test_scoring_random(dev, seed):
         assert st == 0
         refl = O.leverage_scores(k, lens, PHI, normalize=False, chunk_size=512, out_dtype=torch.float32)
         assert torch.allclose(scores.cpu(), refl, rtol=1e-3, atol=2e-4), (seed, (scores.cpu() - refl).abs().max())
+
+
+def test_many_short_sequences(dev):
+    """A batch of 64 short sequences (the batch size of BASELINE.json configs[4]): decode over ragged short caches and
+    a packed prefill of 48 prompts of 1..70 tokens, against the oracle."""
+    from compactor_vllm_amd.attention.sparse_decode_kernel import head_sparse_decode_attention
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    dtype, HQ, HKV, D, PS = torch.bfloat16, 32, 8, 128, 128
+    g = torch.Generator().manual_seed(64)
+    B = 64
+    lens = torch.randint(0, 600, (B, HKV), generator=g, dtype=torch.int32)
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=64)
+    q = torch.randn(B, HQ, D, generator=g).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    out = head_sparse_decode_attention(q.to(dev), kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), HKV,
+                                       PS, scale)
+    torch.cuda.synchronize()
+    ref = O.decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, scale)
+    assert torch.allclose(out.cpu().float(), ref.float(), rtol=1e-6, atol=tol(dtype))
+
+    B2 = 48
+    append = torch.randint(1, 71, (B2,), generator=g).tolist()
+    lens2 = torch.randint(0, 140, (B2, HKV), generator=g, dtype=torch.int32)
+    kc2, vc2, pt2, bm2, _ = mk_paged(B2, HKV, D, PS, lens2, dtype, seed=65)
+    cu = torch.tensor([0] + torch.tensor(append).cumsum(0).tolist(), dtype=torch.int32)
+    N = int(cu[-1])
+    q2 = torch.randn(N, HQ, D, generator=g).to(dtype)
+    k2 = torch.randn(N, HKV, D, generator=g).to(dtype)
+    v2 = torch.randn(N, HKV, D, generator=g).to(dtype)
+    out2 = causal_sparse_varlen_with_cache(q2.to(dev), k2.to(dev), v2.to(dev), kc2.to(dev), vc2.to(dev), lens2.to(dev),
+                                           pt2.to(dev), bm2.to(dev), cu.to(dev), max(append), int(lens2.max()), HKV, PS,
+                                           scale)
+    torch.cuda.synchronize()
+    ref2 = O.prefill_attention(q2, k2, v2, kc2, vc2, lens2, pt2, bm2, cu, HKV, PS, scale)
+    assert torch.allclose(out2.cpu().float(), ref2.float(), rtol=1e-6, atol=tol(dtype))
