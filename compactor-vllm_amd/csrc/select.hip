@@ -277,14 +277,260 @@ __global__ __launch_bounds__(SEL_T) void select_head_kernel(const float* __restr
   }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Multi-workgroup joint selection for long sequences (L*H >= SJ_MIN keys).  The single-workgroup kernel above walks
+// the L*H scores of a sequence three times on ONE CU (288 us at 32 K x 8: instruction-issue bound on that CU); here
+// every radix pass is a histogram kernel over SJ_SLICE-key slices of the flat score array (private LDS histogram,
+// non-zero bins added to a global 4096-bin histogram) followed by a one-workgroup scan that fixes the next digit.
+// Then a slice kernel counts, per head, keys above / equal to the threshold, and a final kernel turns the counts into
+// t_h.  Only when the threshold's ties are kept PARTIALLY (quota < #ties) does the final kernel walk the array once
+// more to take the first `quota` ties in flat-index order (the canonical tie rule).  All sums are integer: the result
+// is deterministic and identical to the single-workgroup path.
+constexpr int SJ_T = 512;
+constexpr int SJ_E = 4;
+constexpr int SJ_SLICE = 8192;   // flat keys per slice workgroup (a multiple of SJ_T * SJ_E)
+constexpr int SJ_MIN = 32768;    // below this many keys per sequence the single-workgroup kernel is used
+struct SjState {
+  uint32_t prefix;
+  int remaining;
+  int fixed_bits;
+  int pad_;
+};
+
+__global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
+                                                       const int* __restrict__ bmap, const SjState* __restrict__ st,
+                                                       uint32_t* __restrict__ gh, int H, int pass, int NS,
+                                                       int reserved) {
+  __shared__ uint32_t hist[SEL_BINS];
+  const int b = blockIdx.x / NS, sl = blockIdx.x % NS;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  if (Lb <= 0 || bmap[b] == reserved) return;
+  const int n = Lb * H;
+  const int beg = sl * SJ_SLICE;
+  if (beg >= n) return;
+  const int end = min(n, beg + SJ_SLICE);
+  const SjState s = st[b];
+  const int fixed_bits = pass == 0 ? 0 : s.fixed_bits;
+  if (fixed_bits >= 32) return;  // retain == 0: nothing to select
+  const int bits = pass < 2 ? 12 : 8;
+  const int shift = 32 - fixed_bits - bits;
+  const uint32_t dmask = (1u << bits) - 1u;
+  const uint32_t prefix = s.prefix;
+  for (int i = tid; i < SEL_BINS; i += SJ_T) hist[i] = 0;
+  __syncthreads();
+  const float* base = scores + (size_t)n0 * H;
+  for (int i0 = beg; i0 < end; i0 += SJ_T * SJ_E) {
+    float x[SJ_E];
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e) {
+      const int i = i0 + tid * SJ_E + e;
+      x[e] = i < end ? base[i] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e) {
+      const int i = i0 + tid * SJ_E + e;
+      const uint32_t key = order_key(x[e]);
+      if (i < end && (fixed_bits == 0 || (key >> (32 - fixed_bits)) == prefix)) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* g = gh + (size_t)b * SEL_BINS;
+  for (int i = tid; i < (1 << bits); i += SJ_T) {
+    const uint32_t c = hist[i];
+    if (c) atomicAdd(&g[i], c);
+  }
+}
+
+__global__ __launch_bounds__(SEL_T) void sj_scan_kernel(const int* __restrict__ cu, const int* __restrict__ bmap,
+                                                        const int* __restrict__ retain, SjState* __restrict__ st,
+                                                        uint32_t* __restrict__ gh, int H, int pass, int reserved) {
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SEL_W];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Lb = cu[b + 1] - cu[b];
+  if (Lb <= 0 || bmap[b] == reserved) return;
+  const int n = Lb * H;
+  uint32_t* g = gh + (size_t)b * SEL_BINS;
+  SjState s = st[b];
+  int remaining;
+  if (pass == 0) {
+    int r = retain[b];
+    r = r < 0 ? 0 : (r > n ? n : r);
+    s.prefix = 0;
+    s.fixed_bits = 0;
+    remaining = r;
+    if (r == 0) {  // keep nothing: a threshold above every key, quota 0
+      if (tid == 0) st[b] = SjState{0xffffffffu, 0, 32, 0};
+      for (int i = tid; i < SEL_BINS; i += SEL_T) g[i] = 0;
+      return;
+    }
+  } else {
+    if (s.fixed_bits >= 32) return;
+    remaining = s.remaining;
+  }
+  const int bits = pass < 2 ? 12 : 8;
+  const int nb = 1 << bits;
+  const int b0 = nb - 1 - 4 * tid;  // thread t owns bins top-4t .. top-4t-3
+  uint32_t c[4] = {0, 0, 0, 0};
+  if (b0 >= 3) {
+    c[0] = g[b0]; c[1] = g[b0 - 1]; c[2] = g[b0 - 2]; c[3] = g[b0 - 3];
+  }
+  const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
+  int tot;
+  const int excl = block_excl_scan_cnt(mine, s_wsum, tot);
+  if (excl < remaining && remaining <= excl + mine) {
+    int acc = excl, d = b0;
+    if (acc + (int)c[0] >= remaining) { d = b0; }
+    else { acc += c[0]; if (acc + (int)c[1] >= remaining) { d = b0 - 1; }
+    else { acc += c[1]; if (acc + (int)c[2] >= remaining) { d = b0 - 2; }
+    else { acc += c[2]; d = b0 - 3; } } }
+    s_state[0] = (uint32_t)d;
+    s_state[1] = (uint32_t)(remaining - acc);
+  }
+  __syncthreads();
+  if (tid == 0) st[b] = SjState{(s.prefix << bits) | s_state[0], (int)s_state[1], s.fixed_bits + bits, 0};
+  for (int i = tid; i < SEL_BINS; i += SEL_T) g[i] = 0;  // ready for the next pass (everyone has read its bins)
+}
+
+// per-head counts of keys above / equal to the threshold over one slice
+__global__ __launch_bounds__(SJ_T) void sj_count_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
+                                                        const int* __restrict__ bmap, const SjState* __restrict__ st,
+                                                        int* __restrict__ cnt_gt, int* __restrict__ cnt_eq, int H,
+                                                        int NS, int reserved) {
+  __shared__ int s_gt[SEL_MAXH], s_eq[SEL_MAXH];
+  const int b = blockIdx.x / NS, sl = blockIdx.x % NS;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  if (Lb <= 0 || bmap[b] == reserved) return;
+  const int n = Lb * H;
+  const int beg = sl * SJ_SLICE;
+  if (beg >= n) return;
+  const int end = min(n, beg + SJ_SLICE);
+  const uint32_t v = st[b].prefix;
+  if (tid < SEL_MAXH) s_gt[tid] = 0, s_eq[tid] = 0;
+  __syncthreads();
+  const float* base = scores + (size_t)n0 * H;
+  // (SJ_T * SJ_E) % H == 0 and SJ_SLICE % H == 0 for H a power of two: element e of thread t is always head
+  // (4t + e) % H, so the counts stay in registers; other H go through LDS atomics
+  const bool fixed_head = ((SJ_T * SJ_E) % H) == 0 && (SJ_SLICE % H) == 0;
+  int lg[SJ_E], le[SJ_E];
+#pragma unroll
+  for (int e = 0; e < SJ_E; ++e) lg[e] = 0, le[e] = 0;
+  for (int i0 = beg; i0 < end; i0 += SJ_T * SJ_E) {
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e) {
+      const int i = i0 + tid * SJ_E + e;
+      if (i < end) {
+        const uint32_t key = order_key(base[i]);
+        if (fixed_head) {
+          lg[e] += key > v ? 1 : 0;
+          le[e] += key == v ? 1 : 0;
+        } else {
+          if (key > v) atomicAdd(&s_gt[i % H], 1);
+          if (key == v) atomicAdd(&s_eq[i % H], 1);
+        }
+      }
+    }
+  }
+  if (fixed_head) {
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e) {
+      const int hh = (tid * SJ_E + e) % H;
+      if (lg[e]) atomicAdd(&s_gt[hh], lg[e]);
+      if (le[e]) atomicAdd(&s_eq[hh], le[e]);
+    }
+  }
+  __syncthreads();
+  if (tid < H) {
+    if (s_gt[tid]) atomicAdd(&cnt_gt[b * SEL_MAXH + tid], s_gt[tid]);
+    if (s_eq[tid]) atomicAdd(&cnt_eq[b * SEL_MAXH + tid], s_eq[tid]);
+  }
+}
+
+__global__ __launch_bounds__(SEL_T) void sj_final_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
+                                                         const int* __restrict__ bh_lens0, const int* __restrict__ bmap,
+                                                         const SjState* __restrict__ st, const int* __restrict__ cnt_gt,
+                                                         const int* __restrict__ cnt_eq, int* __restrict__ target,
+                                                         int* __restrict__ new_lens, int H, int PS, int pad,
+                                                         int reserved) {
+  __shared__ int s_wsum[SEL_W];
+  __shared__ int s_cnt[SEL_MAXH];
+  __shared__ int s_tot_eq;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  if (Lb <= 0 || bmap[b] == reserved) {
+    if (tid < H) {
+      target[b * H + tid] = 0;
+      new_lens[b * H + tid] = bh_lens0[b * H + tid];
+    }
+    return;
+  }
+  const int n = Lb * H;
+  const uint32_t v = st[b].prefix;
+  const int quota = st[b].remaining;
+  if (tid == 0) {
+    int t = 0;
+    for (int hh = 0; hh < H; ++hh) t += cnt_eq[b * SEL_MAXH + hh];
+    s_tot_eq = t;
+  }
+  if (tid < H) s_cnt[tid] = cnt_gt[b * SEL_MAXH + tid];
+  __syncthreads();
+  const int tot_eq = s_tot_eq;
+  if (quota >= tot_eq) {
+    if (tid < H) s_cnt[tid] += cnt_eq[b * SEL_MAXH + tid];
+  } else if (quota > 0) {
+    // partial ties: the first `quota` elements equal to v in ascending flat index are kept
+    const float* base = scores + (size_t)n0 * H;
+    int ties_before = 0;
+    for (int i0 = 0; i0 < n && ties_before < quota; i0 += SEL_T * SEL_E) {
+      bool tie[SEL_E];
+      int ntie = 0;
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        const int i = i0 + tid * SEL_E + e;
+        tie[e] = i < n && order_key(base[i]) == v;
+        ntie += tie[e] ? 1 : 0;
+      }
+      int tot;
+      int tr = ties_before + block_excl_scan_cnt(ntie, s_wsum, tot);
+#pragma unroll
+      for (int e = 0; e < SEL_E; ++e) {
+        if (tie[e] && tr < quota) atomicAdd(&s_cnt[(i0 + tid * SEL_E + e) % H], 1);
+        tr += tie[e] ? 1 : 0;
+      }
+      ties_before += tot;
+    }
+  }
+  __syncthreads();
+  if (tid < H) {
+    const int c = s_cnt[tid];
+    const int L0 = bh_lens0[b * H + tid];
+    const int L = L0 + c;
+    int take = c;
+    if (pad && (L % PS) != 0) {
+      const int need = PS - L % PS;
+      int extra = min(need, min(Lb - L, Lb - c));  // store_kv_cache.py:209-220
+      take += extra > 0 ? extra : 0;
+    }
+    target[b * H + tid] = take;
+    new_lens[b * H + tid] = L0 + take;
+  }
+}
+
 }  // namespace cvllm
 
 using namespace cvllm;
 
 extern "C" size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen) {
-  (void)max_seqlen;
   if (B <= 0 || H <= 0) return 0;
-  return (size_t)B * H * sizeof(int32_t);
+  size_t bytes = ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;  // target[B,H]
+  if ((long)max_seqlen * H >= SJ_MIN)  // multi-workgroup joint path: global histogram, state, per-head counts
+    bytes += (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
+  return bytes;
 }
 
 extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_k, const int32_t* retain,
@@ -299,8 +545,29 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
   if (!workspace || workspace_bytes < cvllm_select_workspace_bytes(B, H, max_seqlen)) return CVLLM_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int* target = (int*)workspace;
-  hipLaunchKernelGGL(select_joint_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, retain, bh_lens0,
-                     batch_mapping, target, new_lens, H, page_size, pad_to_page, reserved_batch);
+  if ((long)max_seqlen * H >= SJ_MIN) {
+    char* p = (char*)workspace + ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;
+    const size_t extra = (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
+    uint32_t* gh = (uint32_t*)p;
+    SjState* sst = (SjState*)(gh + (size_t)B * SEL_BINS);
+    int* cnt_gt = (int*)(sst + B);
+    int* cnt_eq = cnt_gt + (size_t)B * SEL_MAXH;
+    if (hipMemsetAsync(p, 0, extra, st) != hipSuccess) return CVLLM_ERR_LAUNCH;
+    const int NS = (int)(((long)max_seqlen * H + SJ_SLICE - 1) / SJ_SLICE);
+    for (int pass = 0; pass < 3; ++pass) {
+      hipLaunchKernelGGL(sj_hist_kernel, dim3(B * NS), dim3(SJ_T), 0, st, scores, cu_seqlens_k, batch_mapping, sst, gh, H,
+                         pass, NS, reserved_batch);
+      hipLaunchKernelGGL(sj_scan_kernel, dim3(B), dim3(SEL_T), 0, st, cu_seqlens_k, batch_mapping, retain, sst, gh, H,
+                         pass, reserved_batch);
+    }
+    hipLaunchKernelGGL(sj_count_kernel, dim3(B * NS), dim3(SJ_T), 0, st, scores, cu_seqlens_k, batch_mapping, sst,
+                       cnt_gt, cnt_eq, H, NS, reserved_batch);
+    hipLaunchKernelGGL(sj_final_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, bh_lens0, batch_mapping, sst,
+                       cnt_gt, cnt_eq, target, new_lens, H, page_size, pad_to_page, reserved_batch);
+  } else {
+    hipLaunchKernelGGL(select_joint_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, retain, bh_lens0,
+                       batch_mapping, target, new_lens, H, page_size, pad_to_page, reserved_batch);
+  }
   hipLaunchKernelGGL(select_head_kernel, dim3(B * H), dim3(SEL_T), 0, st, scores, cu_seqlens_k, target, kept_idx, H,
                      max_seqlen);
   return check_launch();

@@ -316,3 +316,41 @@ def test_many_short_sequences(dev):
     torch.cuda.synchronize()
     ref2 = O.prefill_attention(q2, k2, v2, kc2, vc2, lens2, pt2, bm2, cu, HKV, PS, scale)
     assert torch.allclose(out2.cpu().float(), ref2.float(), rtol=1e-6, atol=tol(dtype))
+
+
+@pytest.mark.parametrize("kind", ["normal", "quantised", "zeros", "inf_heavy"])
+@pytest.mark.parametrize("H", [8, 6])
+def test_select_long_sequences_multi_workgroup_path(dev, kind, H):
+    """L * H >= 32768 keys per sequence takes the multi-workgroup joint selection (slice histograms + scan per radix
+    pass); mixed with a short sequence and a RESERVED row in the same batch.  Heavy ties exercise the partial-tie walk."""
+    from compactor_vllm_amd.compression.common import select_retained
+    from helpers import kept_sets_from_lists
+
+    PS = 128
+    lens = [5000, 300, 9000, 4100]
+    B = len(lens)
+    g = torch.Generator().manual_seed(77 + H)
+    cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+    N = int(cu[-1])
+    sc = torch.randn(N, H, generator=g)
+    if kind == "quantised":
+        sc = (sc * 2).round() / 2
+    elif kind == "zeros":
+        sc = torch.where(torch.rand(N, H, generator=g) < 0.5, torch.zeros(()), -torch.zeros(()))
+    elif kind == "inf_heavy":
+        sc[torch.rand(N, H, generator=g) < 0.4] = float("inf")
+    for b in range(B):
+        s, L = int(cu[b]), lens[b]
+        sc[s : s + 16] = float("inf")
+        sc[s + L - 64 : s + L] = float("inf")
+    retain = torch.tensor([O.retain_count(0.5, L, 16, 64, H) for L in lens], dtype=torch.int32)
+    retain[3] = lens[3] * H - 5  # nearly everything
+    lens0 = torch.zeros(B, H, dtype=torch.int32)
+    bm = torch.tensor([1, 2, 0, 4], dtype=torch.int32)  # the 9000-token sequence sits on the RESERVED row
+    kept_o, lens_o = O.retained_sets(sc, cu, retain, lens0, bm, PS, True)
+    kept, new_lens = select_retained(sc.to(dev), cu.to(dev), max(lens), retain.to(dev), bm.to(dev), lens0.to(dev), PS,
+                                     True)
+    torch.cuda.synchronize()
+    assert torch.equal(new_lens.cpu(), lens_o), kind
+    sets = kept_sets_from_lists(kept.cpu(), new_lens.cpu(), lens0)
+    assert sets == [sorted(kept_o[b][h]) for b in range(B) for h in range(H)], kind
