@@ -31,8 +31,9 @@ __device__ __forceinline__ uint32_t order_key(float x) {
 constexpr int SEL_E = 4;  // elements per thread per iteration: 4 independent loads in flight (the loops are
                           // L2-latency bound with one), thread t owns the CONSECUTIVE indices base + 4t .. +3
 
-// block-wide exclusive scan of a small per-thread count over SEL_T threads (thread order = index order)
-__device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& total) {
+// block-wide exclusive scan of a small per-thread count over NT threads (thread order = index order)
+template <int NT>
+__device__ __forceinline__ int block_excl_scan_cnt_t(int cnt, int* s_wsum, int& total) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int incl = cnt;
 #pragma unroll
@@ -44,7 +45,7 @@ __device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& to
   __syncthreads();
   int woff = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < SEL_W; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
     const int c = s_wsum[w];
     if (w < wave) woff += c;
     tot += c;
@@ -52,6 +53,9 @@ __device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& to
   __syncthreads();
   total = tot;
   return woff + incl - cnt;
+}
+__device__ __forceinline__ int block_excl_scan_cnt(int cnt, int* s_wsum, int& total) {
+  return block_excl_scan_cnt_t<SEL_T>(cnt, s_wsum, total);
 }
 
 // Exact selection of the r-th largest (1-based, 1 <= r <= n) ordered key among n strided floats: three radix
@@ -343,26 +347,20 @@ __global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(SEL_T) void sj_scan_kernel(const int* __restrict__ cu, const int* __restrict__ bmap,
-                                                        const int* __restrict__ retain, SjState* __restrict__ st,
-                                                        uint32_t* __restrict__ gh, int H, int pass, int reserved) {
-  __shared__ uint32_t s_state[2];
-  __shared__ int s_wsum[SEL_W];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int Lb = cu[b + 1] - cu[b];
-  if (Lb <= 0 || bmap[b] == reserved) return;
-  const int n = Lb * H;
-  uint32_t* g = gh + (size_t)b * SEL_BINS;
-  SjState s = st[b];
+// one radix step on a finished global histogram g[4096]: fixes the next digit of the r-th largest key, updates the
+// state and zeroes the histogram for the next pass.  r0 = the rank to select (used in pass 0), r0 == 0 keeps nothing.
+// All SEL_T threads of the workgroup must call.
+__device__ void radix_scan_step(uint32_t* __restrict__ g, SjState* __restrict__ stp, int r0, int pass,
+                                uint32_t* s_state, int* s_wsum) {
+  const int tid = threadIdx.x;
+  SjState s = *stp;
   int remaining;
   if (pass == 0) {
-    int r = retain[b];
-    r = r < 0 ? 0 : (r > n ? n : r);
     s.prefix = 0;
     s.fixed_bits = 0;
-    remaining = r;
-    if (r == 0) {  // keep nothing: a threshold above every key, quota 0
-      if (tid == 0) st[b] = SjState{0xffffffffu, 0, 32, 0};
+    remaining = r0;
+    if (r0 == 0) {  // keep nothing: a threshold above every key, quota 0
+      if (tid == 0) *stp = SjState{0xffffffffu, 0, 32, 0};
       for (int i = tid; i < SEL_BINS; i += SEL_T) g[i] = 0;
       return;
     }
@@ -390,8 +388,22 @@ __global__ __launch_bounds__(SEL_T) void sj_scan_kernel(const int* __restrict__ 
     s_state[1] = (uint32_t)(remaining - acc);
   }
   __syncthreads();
-  if (tid == 0) st[b] = SjState{(s.prefix << bits) | s_state[0], (int)s_state[1], s.fixed_bits + bits, 0};
+  if (tid == 0) *stp = SjState{(s.prefix << bits) | s_state[0], (int)s_state[1], s.fixed_bits + bits, 0};
   for (int i = tid; i < SEL_BINS; i += SEL_T) g[i] = 0;  // ready for the next pass (everyone has read its bins)
+}
+
+__global__ __launch_bounds__(SEL_T) void sj_scan_kernel(const int* __restrict__ cu, const int* __restrict__ bmap,
+                                                        const int* __restrict__ retain, SjState* __restrict__ st,
+                                                        uint32_t* __restrict__ gh, int H, int pass, int reserved) {
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SEL_W];
+  const int b = blockIdx.x;
+  const int Lb = cu[b + 1] - cu[b];
+  if (Lb <= 0 || bmap[b] == reserved) return;
+  const int n = Lb * H;
+  int r = retain[b];
+  r = r < 0 ? 0 : (r > n ? n : r);
+  radix_scan_step(gh + (size_t)b * SEL_BINS, st + b, r, pass, s_state, s_wsum);
 }
 
 // per-head counts of keys above / equal to the threshold over one slice
@@ -521,6 +533,160 @@ __global__ __launch_bounds__(SEL_T) void sj_final_kernel(const float* __restrict
   }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Multi-workgroup per-head selection + ordered compaction (max_seqlen >= SH_MIN): the same slice-histogram / scan
+// passes per (sequence, head) column, then per-slice kept counts and a write kernel that places every slice's kept
+// token indices behind those of the slices before it (token order is preserved: the list stays ascending).
+constexpr int SH_SLICE = 4096;  // tokens per slice workgroup
+constexpr int SH_MIN = 8192;    // shorter batches keep the one-workgroup-per-head kernel
+constexpr int SH_MAXP = 64;     // slices per column (max_seqlen <= 256 K tokens)
+
+__device__ __forceinline__ int sh_rank(const int* __restrict__ target, int bh, int Lb) {
+  const int t = target[bh];
+  return t < 0 ? 0 : (t > Lb ? Lb : t);
+}
+
+__global__ __launch_bounds__(SJ_T) void sh_hist_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
+                                                       const int* __restrict__ target, const SjState* __restrict__ st,
+                                                       uint32_t* __restrict__ gh, int H, int pass, int P) {
+  __shared__ uint32_t hist[SEL_BINS];
+  const int p = blockIdx.x % P, bh = blockIdx.x / P;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  const int beg = p * SH_SLICE;
+  if (Lb <= 0 || beg >= Lb) return;
+  const int t = sh_rank(target, bh, Lb);
+  if (t <= 0 || t >= Lb) return;  // nothing / everything kept: no threshold needed
+  const int end = min(Lb, beg + SH_SLICE);
+  const SjState s = st[bh];
+  const int fixed_bits = pass == 0 ? 0 : s.fixed_bits;
+  const int bits = pass < 2 ? 12 : 8;
+  const int shift = 32 - fixed_bits - bits;
+  const uint32_t dmask = (1u << bits) - 1u;
+  for (int i = tid; i < SEL_BINS; i += SJ_T) hist[i] = 0;
+  __syncthreads();
+  const float* base = scores + (size_t)n0 * H + h;
+  for (int i = beg + tid; i < end; i += SJ_T) {
+    const uint32_t key = order_key(base[(size_t)i * H]);
+    if (fixed_bits == 0 || (key >> (32 - fixed_bits)) == s.prefix) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  uint32_t* g = gh + (size_t)bh * SEL_BINS;
+  for (int i = tid; i < (1 << bits); i += SJ_T) {
+    const uint32_t c = hist[i];
+    if (c) atomicAdd(&g[i], c);
+  }
+}
+
+__global__ __launch_bounds__(SEL_T) void sh_scan_kernel(const int* __restrict__ cu, const int* __restrict__ target,
+                                                        SjState* __restrict__ st, uint32_t* __restrict__ gh, int H,
+                                                        int pass) {
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SEL_W];
+  const int bh = blockIdx.x, b = bh / H;
+  const int Lb = cu[b + 1] - cu[b];
+  if (Lb <= 0) return;
+  const int t = sh_rank(target, bh, Lb);
+  if (t <= 0 || t >= Lb) return;
+  radix_scan_step(gh + (size_t)bh * SEL_BINS, st + bh, t, pass, s_state, s_wsum);
+}
+
+// slice_cnt[(bh * P + p) * 2 + {0, 1}] = #keys above / equal to the column's threshold in slice p
+__global__ __launch_bounds__(SJ_T) void sh_count_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
+                                                        const int* __restrict__ target, const SjState* __restrict__ st,
+                                                        int* __restrict__ slice_cnt, int H, int P) {
+  __shared__ int s_wsum[SJ_T / 64];
+  const int p = blockIdx.x % P, bh = blockIdx.x / P;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  const int beg = p * SH_SLICE;
+  if (Lb <= 0 || beg >= Lb) return;
+  const int t = sh_rank(target, bh, Lb);
+  if (t <= 0 || t >= Lb) return;
+  const int end = min(Lb, beg + SH_SLICE);
+  const uint32_t v = st[bh].prefix;
+  const float* base = scores + (size_t)n0 * H + h;
+  int gt = 0, eq = 0;
+  for (int i = beg + tid; i < end; i += SJ_T) {
+    const uint32_t key = order_key(base[(size_t)i * H]);
+    gt += key > v ? 1 : 0;
+    eq += key == v ? 1 : 0;
+  }
+  int tg, te;
+  (void)block_excl_scan_cnt_t<SJ_T>(gt, s_wsum, tg);
+  (void)block_excl_scan_cnt_t<SJ_T>(eq, s_wsum, te);
+  if (tid == 0) {
+    slice_cnt[((size_t)bh * P + p) * 2] = tg;
+    slice_cnt[((size_t)bh * P + p) * 2 + 1] = te;
+  }
+}
+
+__global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
+                                                        const int* __restrict__ target, const SjState* __restrict__ st,
+                                                        const int* __restrict__ slice_cnt, int* __restrict__ kept_idx,
+                                                        int H, int P, int max_seqlen) {
+  __shared__ int s_wsum[SJ_T / 64];
+  const int p = blockIdx.x % P, bh = blockIdx.x / P;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x;
+  const int n0 = cu[b];
+  const int Lb = cu[b + 1] - n0;
+  const int beg = p * SH_SLICE;
+  if (Lb <= 0 || beg >= Lb) return;
+  const int t = sh_rank(target, bh, Lb);
+  if (t <= 0) return;
+  const int end = min(Lb, beg + SH_SLICE);
+  int* list = kept_idx + (size_t)bh * max_seqlen;
+  if (t >= Lb) {
+    for (int i = beg + tid; i < end; i += SJ_T) list[i] = i;
+    return;
+  }
+  const uint32_t v = st[bh].prefix;
+  const int quota = st[bh].remaining;
+  // kept tokens and ties in the slices before this one (P <= 64: every thread walks the few counters itself)
+  int ties_before = 0, kept_before = 0;
+  for (int q = 0; q < p; ++q) {
+    const int g = slice_cnt[((size_t)bh * P + q) * 2], e = slice_cnt[((size_t)bh * P + q) * 2 + 1];
+    const int room = quota - ties_before;
+    kept_before += g + (room > 0 ? min(e, room) : 0);
+    ties_before += e;
+  }
+  const float* base = scores + (size_t)n0 * H + h;
+  for (int i0 = beg; i0 < end; i0 += SJ_T * SJ_E) {
+    uint32_t key[SJ_E];
+    bool in[SJ_E];
+    int ntie = 0;
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e) {
+      const int i = i0 + tid * SJ_E + e;
+      in[e] = i < end;
+      key[e] = in[e] ? order_key(base[(size_t)i * H]) : 0u;
+      ntie += (in[e] && key[e] == v) ? 1 : 0;
+    }
+    int tot_t, tot_k;
+    int tr = ties_before + block_excl_scan_cnt_t<SJ_T>(ntie, s_wsum, tot_t);
+    bool keep[SJ_E];
+    int nkeep = 0;
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e) {
+      const bool tie = in[e] && key[e] == v;
+      keep[e] = in[e] && (key[e] > v || (tie && tr < quota));
+      tr += tie ? 1 : 0;
+      nkeep += keep[e] ? 1 : 0;
+    }
+    int slot = kept_before + block_excl_scan_cnt_t<SJ_T>(nkeep, s_wsum, tot_k);
+#pragma unroll
+    for (int e = 0; e < SJ_E; ++e)
+      if (keep[e]) list[slot++] = i0 + tid * SJ_E + e;
+    ties_before += tot_t;
+    kept_before += tot_k;
+  }
+}
+
 }  // namespace cvllm
 
 using namespace cvllm;
@@ -530,6 +696,10 @@ extern "C" size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen) {
   size_t bytes = ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;  // target[B,H]
   if ((long)max_seqlen * H >= SJ_MIN)  // multi-workgroup joint path: global histogram, state, per-head counts
     bytes += (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
+  if (max_seqlen >= SH_MIN) {  // multi-workgroup per-head path: per-column histogram + state, per-slice counts
+    const size_t P = ((size_t)max_seqlen + SH_SLICE - 1) / SH_SLICE;
+    bytes += (size_t)B * H * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + P * 2 * sizeof(int32_t));
+  }
   return bytes;
 }
 
@@ -568,7 +738,28 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
     hipLaunchKernelGGL(select_joint_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, retain, bh_lens0,
                        batch_mapping, target, new_lens, H, page_size, pad_to_page, reserved_batch);
   }
-  hipLaunchKernelGGL(select_head_kernel, dim3(B * H), dim3(SEL_T), 0, st, scores, cu_seqlens_k, target, kept_idx, H,
-                     max_seqlen);
+  const int P = (max_seqlen + SH_SLICE - 1) / SH_SLICE;
+  if (max_seqlen >= SH_MIN && P <= SH_MAXP) {
+    char* p = (char*)workspace + ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;
+    if ((long)max_seqlen * H >= SJ_MIN)
+      p += (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
+    uint32_t* gh2 = (uint32_t*)p;
+    SjState* st2 = (SjState*)(gh2 + (size_t)B * H * SEL_BINS);
+    int* slice_cnt = (int*)(st2 + (size_t)B * H);
+    if (hipMemsetAsync(p, 0, (size_t)B * H * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState)), st) != hipSuccess)
+      return CVLLM_ERR_LAUNCH;
+    for (int pass = 0; pass < 3; ++pass) {
+      hipLaunchKernelGGL(sh_hist_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, gh2, H,
+                         pass, P);
+      hipLaunchKernelGGL(sh_scan_kernel, dim3(B * H), dim3(SEL_T), 0, st, cu_seqlens_k, target, st2, gh2, H, pass);
+    }
+    hipLaunchKernelGGL(sh_count_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, slice_cnt,
+                       H, P);
+    hipLaunchKernelGGL(sh_write_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, slice_cnt,
+                       kept_idx, H, P, max_seqlen);
+  } else {
+    hipLaunchKernelGGL(select_head_kernel, dim3(B * H), dim3(SEL_T), 0, st, scores, cu_seqlens_k, target, kept_idx, H,
+                       max_seqlen);
+  }
   return check_launch();
 }
