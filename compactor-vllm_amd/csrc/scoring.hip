@@ -120,7 +120,8 @@ __global__ void fill_inf_kernel(void* __restrict__ x, const int* __restrict__ ra
 // =====================================================================================================
 constexpr int CM_CHUNK = 128;
 template <typename T, int D, int G>
-__global__ __launch_bounds__(256) void chunk_mass_kernel(const uint16_t* __restrict__ q,
+// min 2 waves per SIMD: left alone hipcc spends 272 registers (1 wave per SIMD = ONE workgroup per CU; measured 180 us)
+__global__ __launch_bounds__(256, 2) void chunk_mass_kernel(const uint16_t* __restrict__ q,
                                                          const uint16_t* __restrict__ k, int64_t sq_n, int64_t sk_n,
                                                          int64_t sk_h, float* __restrict__ mass,
                                                          const int* __restrict__ cu, int B, int HKV, int nchunk_max,
@@ -434,6 +435,8 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
       t *= s_Li[kk];
       y[kk] = t;
       sc = fmaf(t, t, sc);
+      // keep hipcc from hoisting the L loads of all 48 steps to the top (381 registers = one workgroup per CU)
+      __builtin_amdgcn_sched_barrier(0);
     }
     scores[(size_t)(beg + i) * HKV + hh] = fmaxf(sc, 0.f);
   }
