@@ -83,6 +83,41 @@ __global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ 
   dp[l + 64] = f2bf(b * c + a * s);
 }
 
+// RoPE without q/k-norm, vectorised: a thread rotates 8 + 8 elements (dims 8c.. and 64 + 8c..) of one (token, head)
+// with 16-byte loads / stores (the wave-per-head kernel above moves 2-byte elements: 0.40 ms per 32 K-token layer where
+// the bytes need 0.13 ms)
+__global__ __launch_bounds__(256) void rope_vec_kernel(const uint16_t* __restrict__ src, int64_t s_n,
+                                                       uint16_t* __restrict__ dst, const int64_t* __restrict__ pos,
+                                                       const float* __restrict__ cs, long total, int H) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;  // (n, hh, c) with c in [0, 8)
+  if (e >= total) return;
+  const int c = (int)(e & 7);
+  const long nh = e >> 3;
+  const int hh = (int)(nh % H);
+  const long n = nh / H;
+  const uint16_t* sp = src + (size_t)n * s_n + (size_t)hh * 128 + c * 8;
+  const uint4 av = *reinterpret_cast<const uint4*>(sp), bv = *reinterpret_cast<const uint4*>(sp + 64);
+  const float* t = cs + (size_t)pos[n] * 128 + c * 8;  // [cos(64) | sin(64)]
+  const float4 c0 = *reinterpret_cast<const float4*>(t), c1 = *reinterpret_cast<const float4*>(t + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(t + 64), s1 = *reinterpret_cast<const float4*>(t + 68);
+  const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const uint16_t* ap = reinterpret_cast<const uint16_t*>(&av);
+  const uint16_t* bp = reinterpret_cast<const uint16_t*>(&bv);
+  uint4 oa, ob;
+  uint16_t* oap = reinterpret_cast<uint16_t*>(&oa);
+  uint16_t* obp = reinterpret_cast<uint16_t*>(&ob);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = bf2f(ap[j]), b = bf2f(bp[j]);
+    oap[j] = f2bf(a * cc[j] - b * ss[j]);
+    obp[j] = f2bf(b * cc[j] + a * ss[j]);
+  }
+  uint16_t* dp = dst + ((size_t)n * H + hh) * 128 + c * 8;
+  *reinterpret_cast<uint4*>(dp) = oa;
+  *reinterpret_cast<uint4*>(dp + 64) = ob;
+}
+
 // out[n, i] = silu(gu[n, i]) * gu[n, I + i]
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out,
                                                        long total, int I) {
@@ -471,6 +506,12 @@ extern "C" void shell_add_rmsnorm(void* h, const void* delta, const void* w, voi
 extern "C" void shell_rope(const void* src, int64_t s_n, void* dst, const void* pos, const void* cs, const void* nwq,
                            const void* nwk, int N, int H, int HQ, float eps, void* stream) {
   const long waves = (long)N * H;
+  if (waves > 0 && !nwq && !nwk && (s_n % 8) == 0 && N >= 64) {  // no q/k-norm, many tokens: 16-byte lanes
+    const long total = waves * 8;
+    hipLaunchKernelGGL(rope_vec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)src, s_n, (uint16_t*)dst, (const int64_t*)pos, (const float*)cs, total, H);
+    return;
+  }
   if (waves > 0)
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)src, s_n, (uint16_t*)dst, (const int64_t*)pos, (const float*)cs,
