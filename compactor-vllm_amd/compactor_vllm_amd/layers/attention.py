@@ -27,123 +27,89 @@ from ..utils.helpers import maybe_execute_in_stream
 
 
 class Attention(nn.Module):
+    """Constructor signature and the attributes a cache manager injects are the reference's (`:17-36`); `forward`
+    dispatches to one method per phase."""
+
     def __init__(self, num_heads, head_dim, scale, num_kv_heads):
         super().__init__()
         self.num_heads: int = num_heads
         self.head_dim = head_dim
         self.scale: float = scale
         self.num_kv_heads = int(num_kv_heads)
-
-        # injected by the cache manager (reference memory_manager.py:82-90): views into PagedKVCache buffers
-        self.k_cache: Optional[torch.Tensor] = None
-        self.v_cache: Optional[torch.Tensor] = None
-        self.page_table: Optional[torch.Tensor] = None
-        self.bh_seq_lens: Optional[torch.Tensor] = None
-        self.page_size: Optional[int] = None
+        # views into the PagedKVCache buffers, set per layer by whoever owns the cache (reference
+        # memory_manager.py:82-90); None until then
+        for name in ("k_cache", "v_cache", "page_table", "bh_seq_lens", "page_size"):
+            setattr(self, name, None)
         self.fused_decode: bool = True  # False = the reference's four-call decode sequence
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _cache_args(self) -> dict:
+        return dict(page_table=self.page_table, k_cache=self.k_cache, v_cache=self.v_cache, PAGE_SIZE=self.page_size)
+
+    def _gathered_lengths(self, batch_mapping) -> Optional[torch.Tensor]:
+        """[B, HKV] copy of this layer's lengths for the rows of the batch (the reference's `seq_lens`)."""
+        if self.bh_seq_lens is None:
+            return None
+        return self.bh_seq_lens.index_select(0, batch_mapping).contiguous()
+
+    def _write_back_lengths(self, context: Context, batch_mapping, seq_lens) -> None:
+        if self.bh_seq_lens is None:
+            return
+        maybe_execute_in_stream(self.bh_seq_lens.index_copy_, 0, batch_mapping.to(torch.long), seq_lens,
+                                STORE_STREAM=context.STORE_STREAM if context.is_prefill else None)
+
+    # ------------------------------------------------------------------------------------------------ phases
+    def _prefill(self, context: Context, q, k, v, scores, seq_lens):
+        """Cache write (compacted or full) on the store stream, attention over [old prefix || new block] on the main
+        stream with the lengths as they were BEFORE the write."""
+        if context.attention_backend != AttentionBackend.COMPACTOR_TRITON:
+            raise NotImplementedError("only the native (COMPACTOR_TRITON-slot) backend exists in this build")
+        assert self.k_cache is not None, "KV cache must be initialised"
+        batch_mapping = context.batch_mapping
+        lengths_before = seq_lens.clone()
+        common = dict(self._cache_args(), batch_mapping=batch_mapping, bh_lens=seq_lens,
+                      STORE_STREAM=context.STORE_STREAM)
+        compress = context.do_compression and scores is not None
+        if compress:
+            cc = context.compression_context
+            assert cc is not None
+            maybe_execute_in_stream(
+                extract_and_store_top_kv, scores=scores, cu_seqlens_k=context.cu_seqlens_k,
+                max_k_len=context.max_seqlen_k, top_k=cc.max_tokens_to_retain, H=int(self.num_kv_heads), new_keys=k,
+                new_vals=v, num_tokens_to_retain=cc.batch_tokens_to_retain, PAD_TO_PAGE_SIZE=True, **common)
+        else:
+            maybe_execute_in_stream(
+                prefill_store_all_kv, new_keys=k, new_values=v, cu_seqlens_k=context.cu_seqlens_k,
+                max_seqlen_k=context.max_seqlen_k, **common)
+        return causal_sparse_varlen_with_cache(
+            q, k, v, self.k_cache, self.v_cache, seq_lens_bh=lengths_before, global_page_table=self.page_table,
+            batch_mapping=batch_mapping, cu_seqlens_q=context.cu_seqlens_q, max_seqlen_q=context.max_seqlen_q,
+            max_seqlen_k_cache=context.max_bh_len, HKV=int(self.num_kv_heads), PAGE_SIZE=self.page_size,
+            sm_scale=self.scale)
+
+    def _decode_reference_order(self, context: Context, q, k, v, seq_lens):
+        """append the token's K/V row, then attend over the whole cache (reference `:127-150`)"""
+        assert self.k_cache is not None, "KV Cache must be initialized for decoding"
+        batch_mapping = context.batch_mapping
+        decode_store_kv(key=k, value=v, batch_mapping=batch_mapping, bh_lens=seq_lens, **self._cache_args())
+        return head_sparse_decode_attention(q, self.k_cache, self.v_cache, seq_lens, self.page_table, batch_mapping,
+                                            int(self.num_kv_heads), self.page_size, self.scale,
+                                            key_split=context.key_split)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scores: Optional[torch.Tensor] = None):
         context: Context = get_context()
         batch_mapping = context.batch_mapping
         if not context.is_prefill and self.fused_decode and self.bh_seq_lens is not None:
-            # store-then-attend on the layer's own length table: one C-ABI call instead of
+            # store-then-attend directly on the layer's length table: one C-ABI call instead of
             # index_select + decode_store_kv + attention + index_copy_ (same results, 3 fewer launches)
             assert self.k_cache is not None, "KV Cache must be initialized for decoding"
-            return fused_decode_step(
-                q, k, v, self.k_cache, self.v_cache, self.bh_seq_lens, self.page_table, batch_mapping,
-                int(self.num_kv_heads), self.page_size, self.scale, key_split=context.key_split,
-            )
-        seq_lens = (
-            None if self.bh_seq_lens is None else self.bh_seq_lens.index_select(0, batch_mapping).contiguous()
-        )
+            return fused_decode_step(q, k, v, self.k_cache, self.v_cache, self.bh_seq_lens, self.page_table,
+                                     batch_mapping, int(self.num_kv_heads), self.page_size, self.scale,
+                                     key_split=context.key_split)
+        seq_lens = self._gathered_lengths(batch_mapping)
         if context.is_prefill:
-            if context.attention_backend != AttentionBackend.COMPACTOR_TRITON:
-                raise NotImplementedError("only the native (COMPACTOR_TRITON-slot) backend exists in this build")
-            assert self.k_cache is not None, "KV cache must be initialised"
-            seq_lens_copy = seq_lens.clone()  # pre-store lengths: what the attention kernel must see
-            if context.do_compression and scores is not None:
-                cc = context.compression_context
-                assert cc is not None
-                maybe_execute_in_stream(
-                    extract_and_store_top_kv,
-                    scores=scores,
-                    cu_seqlens_k=context.cu_seqlens_k,
-                    max_k_len=context.max_seqlen_k,
-                    top_k=cc.max_tokens_to_retain,
-                    H=int(self.num_kv_heads),
-                    new_keys=k,
-                    new_vals=v,
-                    num_tokens_to_retain=cc.batch_tokens_to_retain,
-                    page_table=self.page_table,
-                    batch_mapping=batch_mapping,
-                    bh_lens=seq_lens,
-                    k_cache=self.k_cache,
-                    v_cache=self.v_cache,
-                    PAGE_SIZE=self.page_size,
-                    PAD_TO_PAGE_SIZE=True,
-                    STORE_STREAM=context.STORE_STREAM,
-                )
-            else:
-                maybe_execute_in_stream(
-                    prefill_store_all_kv,
-                    new_keys=k,
-                    new_values=v,
-                    cu_seqlens_k=context.cu_seqlens_k,
-                    max_seqlen_k=context.max_seqlen_k,
-                    k_cache=self.k_cache,
-                    v_cache=self.v_cache,
-                    page_table=self.page_table,
-                    bh_lens=seq_lens,
-                    batch_mapping=batch_mapping,
-                    PAGE_SIZE=self.page_size,
-                    STORE_STREAM=context.STORE_STREAM,
-                )
-            o = causal_sparse_varlen_with_cache(
-                q,
-                k,
-                v,
-                self.k_cache,
-                self.v_cache,
-                seq_lens_bh=seq_lens_copy,
-                global_page_table=self.page_table,
-                batch_mapping=batch_mapping,
-                cu_seqlens_q=context.cu_seqlens_q,
-                max_seqlen_q=context.max_seqlen_q,
-                max_seqlen_k_cache=context.max_bh_len,
-                HKV=int(self.num_kv_heads),
-                PAGE_SIZE=self.page_size,
-                sm_scale=self.scale,
-            )
+            o = self._prefill(context, q, k, v, scores, seq_lens)
         else:
-            assert self.k_cache is not None, "KV Cache must be initialized for decoding"
-            decode_store_kv(
-                key=k,
-                value=v,
-                batch_mapping=batch_mapping,
-                bh_lens=seq_lens,
-                page_table=self.page_table,
-                k_cache=self.k_cache,
-                v_cache=self.v_cache,
-                PAGE_SIZE=self.page_size,
-            )
-            o = head_sparse_decode_attention(
-                q,
-                self.k_cache,
-                self.v_cache,
-                seq_lens,
-                self.page_table,
-                batch_mapping,
-                int(self.num_kv_heads),
-                self.page_size,
-                self.scale,
-                key_split=context.key_split,
-            )
-        if self.bh_seq_lens is not None:
-            maybe_execute_in_stream(
-                self.bh_seq_lens.index_copy_,
-                0,
-                batch_mapping.to(torch.long),
-                seq_lens,
-                STORE_STREAM=context.STORE_STREAM if context.is_prefill else None,
-            )
+            o = self._decode_reference_order(context, q, k, v, seq_lens)
+        self._write_back_lengths(context, batch_mapping, seq_lens)
         return o

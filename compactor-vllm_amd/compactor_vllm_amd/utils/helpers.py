@@ -1,31 +1,36 @@
-"""Stream helper of the boundary (`compactor_vllm/utils/helpers.py:6-28`), with real dependency edges."""
+"""`maybe_execute_in_stream`: run a piece of the cache / scoring chain on the side ("store") stream.
+
+Calling convention of `compactor_vllm/utils/helpers.py:6-28` (positional / keyword arguments are forwarded, the
+keyword-only `STORE_STREAM=None` means "run inline").  What it guarantees here:
+  * the side stream first waits for everything already enqueued on the caller's stream (inputs are ready);
+  * tensors passed in are marked as in use on the side stream and tensor results as in use on the caller's stream
+    (caching-allocator lifetime - NOT an execution dependency);
+  * a consumer on another stream must still `wait_stream(STORE_STREAM)` before reading a result; the places that need
+    it do so explicitly (the reference has one such edge missing, hazard H1 of SURVEY 3.1 - see compression/compactor.py).
+"""
 from collections.abc import Callable
+from itertools import chain
 
 import torch
 
 
-def maybe_execute_in_stream(fn: Callable, *args, STORE_STREAM: torch.cuda.Stream = None, **kwargs):
-    """Run `fn` on STORE_STREAM (after everything already enqueued on the current stream), or inline.
+def _tensors_in(values):
+    return [x for x in values if isinstance(x, torch.Tensor)]
 
-    Same calling convention as the reference.  The reference orders store-after-main with
-    `wait_stream(default_stream)` and then only calls `record_stream` (allocator lifetime) on the outputs;
-    consumers on the main stream must add their own `wait_stream(STORE_STREAM)` before reading the result
-    (the reference forgets this for Compactor's pre-RoPE scores, hazard H1 — see compactor.py here)."""
+
+def maybe_execute_in_stream(fn: Callable, *args, STORE_STREAM: torch.cuda.Stream = None, **kwargs):
     if STORE_STREAM is None:
         return fn(*args, **kwargs)
-    cur = torch.cuda.current_stream()
-    tensors = [a for a in args if isinstance(a, torch.Tensor)]
-    tensors += [v for v in kwargs.values() if isinstance(v, torch.Tensor)]
-    obj = getattr(fn, "__self__", None)
-    if isinstance(obj, torch.Tensor):
-        tensors.append(obj)
-    STORE_STREAM.wait_stream(cur)
+    caller = torch.cuda.current_stream()
+    STORE_STREAM.wait_stream(caller)
     with torch.cuda.stream(STORE_STREAM):
-        output = fn(*args, **kwargs)
-    for t in tensors:
+        result = fn(*args, **kwargs)
+    inputs = _tensors_in(chain(args, kwargs.values()))
+    bound_to = getattr(fn, "__self__", None)  # e.g. tensor.index_copy_
+    if isinstance(bound_to, torch.Tensor):
+        inputs.append(bound_to)
+    for t in inputs:
         t.record_stream(STORE_STREAM)
-    outs = output if isinstance(output, tuple) else (output,)
-    for o in outs:
-        if isinstance(o, torch.Tensor):
-            o.record_stream(cur)
-    return output
+    for t in _tensors_in(result if isinstance(result, tuple) else (result,)):
+        t.record_stream(caller)
+    return result
