@@ -20,12 +20,13 @@ def _identity_cache(B, HKV, D, PS, L, dtype, dev):
     return kc, vc, pt, bm, P
 
 
-def test_select_32k_exact_vs_topk(dev):
-    """C3 size (32768 tokens x 8 heads, retain 50 %): the kept set must equal torch.topk's set (tie-free
-    random scores) plus, per head, that head's next-best tokens up to a page boundary."""
+@pytest.mark.parametrize("L", [32768, 131072 - 256])
+def test_select_full_size_exact_vs_topk(dev, L):
+    """C3 size (32768 tokens x 8 heads) and the 128 K context of configs[4], retain 50 %: the kept set must equal
+    torch.topk's set (tie-free random scores) plus, per head, that head's next-best tokens up to a page boundary."""
     from compactor_vllm_amd.compression.common import select_retained
 
-    L, H, PS = 32768, 8, 128
+    H, PS = 8, 128
     g = torch.Generator(device=dev).manual_seed(3)
     sc = torch.randn(L, H, device=dev, generator=g)
     sc[:16] = float("inf")
