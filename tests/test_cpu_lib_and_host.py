@@ -141,3 +141,52 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# the oracle", ""), f"{f} mentions the oracle"
+
+
+def test_context_records_and_setters():
+    """`Context` / `CompressionContext` keep the reference's attribute names and defaults (utils/context.py:9-52 there);
+    set_context is keyword-only, replaces the whole record and rejects unknown names."""
+    from compactor_vllm_amd.compression import COMPRESSION_REGISTRY, CompressionMethod
+    from compactor_vllm_amd.config.engine_config import AttentionBackend
+    from compactor_vllm_amd.utils import context as C
+
+    assert [m.name for m in CompressionMethod] == ["COMPACTOR", "SNAPKV", "NONE"]
+    assert [m.value for m in CompressionMethod] == [1, 2, 3]
+    assert set(COMPRESSION_REGISTRY) == set(CompressionMethod)
+    cc = C.CompressionContext()
+    assert (cc.compression_method, cc.compression_chunk_size, cc.max_tokens_to_retain) == (CompressionMethod.COMPACTOR,
+                                                                                           -1, 0)
+    assert cc.batch_tokens_to_retain is None and cc.PHI is None and cc.context_lens is None
+    assert cc.protected_first_tokens is None and cc.protected_last_tokens is None
+    C.reset_context()
+    d = C.get_context()
+    assert (d.is_prefill, d.do_compression, d.max_seqlen_q, d.max_seqlen_k, d.max_bh_len) == (False, False, 0, 0, 0)
+    assert d.attention_backend == AttentionBackend.COMPACTOR_TRITON and d.STORE_STREAM is None and d.key_split is None
+    bm = torch.ones(2, dtype=torch.int32)
+    C.set_context(is_prefill=True, do_compression=True, batch_mapping=bm, max_seqlen_q=7, compression_context=cc)
+    e = C.get_context()
+    assert e.is_prefill and e.do_compression and e.batch_mapping is bm and e.max_seqlen_q == 7
+    assert e.compression_context is cc and e.cu_seqlens_q is None
+    C.set_context(is_prefill=False)  # a NEW record: nothing carries over
+    f = C.get_context()
+    assert not f.is_prefill and f.batch_mapping is None and f.max_seqlen_q == 0
+    with pytest.raises(TypeError):
+        C.set_context(is_prefill=False, no_such_field=1)
+    with pytest.raises(TypeError):
+        C.set_context(True)  # keyword-only
+    C.reset_context()
+
+
+def test_compression_params_defaults_and_snapkv_rule():
+    from compactor_vllm_amd.compression import BatchCompressionParams, CompressionMethod, SequenceCompressionParams
+    from compactor_vllm_amd.config.sampling_params import SamplingParams
+
+    s = SequenceCompressionParams()
+    assert (s.compression_ratio, s.protected_first_tokens, s.protected_last_tokens) == (1.0, 16, 64)
+    b = BatchCompressionParams()
+    assert (b.compression_method, b.do_chunked_compression, b.chunk_size) == (CompressionMethod.COMPACTOR, True, 512)
+    assert BatchCompressionParams(compression_method=CompressionMethod.SNAPKV).do_chunked_compression is False
+    p = SamplingParams()
+    assert (p.temperature, p.max_new_tokens) == (1.0, 256)
+    with pytest.raises(ValueError):
+        SamplingParams(temperature=-0.1)
