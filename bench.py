@@ -364,42 +364,53 @@ def main():
         copy_bw = copy_bandwidth_gbs(dev)
         result["roofline"]["copy_bw"] = round(copy_bw, 1)  # measured device copy rate: the practical HBM roof
         result["roofline"]["frac_of_copy_bw"] = round(result["roofline"]["achieved"] / copy_bw, 4)
-        result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
+        try:
+            result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
+        except Exception as exc:  # noqa: BLE001 - secondary object, see above
+            result["roofline_prefill"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         for bi in state["rows"]:
             model.cache.free_batch(bi)
         if multi_leg:
-            mp = prompts + [torch.randint(0, cfg.vocab, (ctx,), generator=g) for _ in range(MULTI - 1)]
+            # an extra leg must never cost the main line: anything going wrong here is reported, not raised
+            try:
+                mp = prompts + [torch.randint(0, cfg.vocab, (ctx,), generator=g) for _ in range(MULTI - 1)]
 
-            def mstep(keep=None):
-                return model.generate(mp, new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
+                def mstep(keep=None):
+                    return model.generate(mp, new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
 
-            torch.cuda.empty_cache()  # the 1-sequence legs leave the caching allocator fragmented for 4x tensors
-            mstep()
-            torch.cuda.synchronize()
-            dts = []  # two timed steps, the faster one is reported (the first 4x-sized step after the 1-sequence
-            for _ in range(2):  # legs still pays caching-allocator growth: 4.3 vs 5.7 s observed)
-                for bi in (mstate["rows"] if dts else []):
-                    model.cache.free_batch(bi)
-                t1 = time.perf_counter()
-                mstate = {}
-                mstep(mstate)
+                torch.cuda.empty_cache()  # the 1-sequence legs leave the caching allocator fragmented for 4x tensors
+                mstep()
                 torch.cuda.synchronize()
-                dts.append(time.perf_counter() - t1)
-            dt = min(dts)
-            mr = roofline_decode_attn(model, mstate, "-")
-            for bi in mstate["rows"]:
-                model.cache.free_batch(bi)
-            result["multi_sequence"] = {
-                "sequences_per_gpu": MULTI, "value": round(MULTI * (ctx + new) / dt, 1), "unit": "tokens/s",
-                "ms_per_step": round(dt * 1e3, 2), "steps": 2, "ms_per_step_all": [round(x * 1e3, 1) for x in dts],
-                "roofline": {k: mr[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
-                                                "avg_launch_us", "algorithmic_bytes_per_launch")},
-                "note": "same workload with 4 sequences per GPU (packed varlen prefill, batched decode): not the "
-                        "metric's configuration, shown because the decode-attention launch is then 273 MB instead "
-                        "of 68 MB",
-            }
+                dts = []  # two timed steps, the faster one is reported (the first 4x-sized step after the 1-sequence
+                for _ in range(2):  # legs still pays caching-allocator growth: 4.3 vs 5.7 s observed)
+                    for bi in (mstate["rows"] if dts else []):
+                        model.cache.free_batch(bi)
+                    t1 = time.perf_counter()
+                    mstate = {}
+                    mstep(mstate)
+                    torch.cuda.synchronize()
+                    dts.append(time.perf_counter() - t1)
+                dt = min(dts)
+                mr = roofline_decode_attn(model, mstate, "-")
+                for bi in mstate["rows"]:
+                    model.cache.free_batch(bi)
+                result["multi_sequence"] = {
+                    "sequences_per_gpu": MULTI, "value": round(MULTI * (ctx + new) / dt, 1), "unit": "tokens/s",
+                    "ms_per_step": round(dt * 1e3, 2), "steps": 2, "ms_per_step_all": [round(x * 1e3, 1) for x in dts],
+                    "roofline": {k: mr[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                    "avg_launch_us", "algorithmic_bytes_per_launch")},
+                    "note": "same workload with 4 sequences per GPU (packed varlen prefill, batched decode): not the "
+                            "metric's configuration, shown because the decode-attention launch is then 273 MB instead "
+                            "of 68 MB",
+                }
+            except Exception as exc:  # noqa: BLE001
+                result["multi_sequence"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:  # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                                          "sample": f"failed: {type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
