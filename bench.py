@@ -56,23 +56,24 @@ def hip_events(n):
 
 
 def roofline_decode_attn(model, state, workload, rounds=5):
-    """Achieved HBM GB/s of decode_fused_kernel on the REAL post-prefill cache of every layer (distinct memory per
-    layer, 2.2 GB per pass => cold L2 / Infinity Cache, like inside a decode step).  One HIP graph holds the kernel's
-    launches of all layers back to back (the merge kernel is switched off through the library's debug hook, so
-    nothing else runs in between); `rounds` replays of it are queued on the current stream between ONE pair of HIP
-    events recorded on that stream, and per-launch time = elapsed / (rounds * layers).  That includes the dispatch gap
-    between consecutive launches, so it is an upper bound of rocprofv3's kernel duration (profiles/) and the reported
-    fraction a lower bound.  (Event-record nodes captured INSIDE a graph do not refresh the events' timestamps on
-    this ROCm - hipEventElapsedTime keeps returning the last eager recording - so the events stay outside.)"""
-    from compactor_vllm_amd import _lib
-    from compactor_vllm_amd.attention.sparse_decode_kernel import head_sparse_decode_attention
+    """Achieved HBM GB/s of decode attention AS THE REFERENCE DEFINES IT (a2 = stage 1 + split merge,
+    cv/attention/sparse_decode_kernel.py:246-435) on the REAL post-prefill cache of every layer (distinct memory per
+    layer, 2.2 GB per pass => cold L2 / Infinity Cache, like inside a decode step).
+
+    The product call `head_sparse_decode_attention` is captured for all layers back to back into one HIP graph -
+    nothing is switched off: on this workload it is ONE kernel per layer (decode_fused_kernel streams K/V and merges
+    its splits in the same launch); on grids that oversubscribe the chip it would be that kernel plus
+    decode_stage2_kernel, and both would be inside the timed region.  `rounds` replays are queued on the current stream
+    between ONE pair of HIP events recorded on that stream; per-launch time = elapsed / (rounds * layers).  That
+    includes the dispatch gap between consecutive launches, so it is an upper bound of the rocprofv3 kernel durations
+    (profiles/) and the reported fraction a lower bound.  (Event-record nodes captured INSIDE a graph do not refresh
+    the events' timestamps on this ROCm, so the events stay outside.)"""
+    from compactor_vllm_amd.attention import sparse_decode_kernel as dk
 
     cfg, dev = model.cfg, model.dev
     bm = state["bm"]
     B = bm.numel()
     q = torch.randn(B, cfg.heads, cfg.head_dim, device=dev, dtype=torch.bfloat16)
-    L = _lib.lib()
-    L.cvllm_debug_set_decode_stage2.argtypes = [ctypes.c_int]
     nl = cfg.layers
     elt = 2
     bytes_alg = []
@@ -83,18 +84,14 @@ def roofline_decode_attn(model, state, workload, rounds=5):
 
     def one_pass():
         for li, a in enumerate(model.attn):
-            head_sparse_decode_attention(q, a.k_cache, a.v_cache, lens_all[li], a.page_table, bm, cfg.kv_heads,
-                                         a.page_size)
+            dk.head_sparse_decode_attention(q, a.k_cache, a.v_cache, lens_all[li], a.page_table, bm, cfg.kv_heads,
+                                            a.page_size)
 
     one_pass()  # warm-up (workspace allocation)
     torch.cuda.synchronize()
-    L.cvllm_debug_set_decode_stage2(0)
-    try:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            one_pass()
-    finally:
-        L.cvllm_debug_set_decode_stage2(1)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        one_pass()
     graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -103,16 +100,25 @@ def roofline_decode_attn(model, state, workload, rounds=5):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
+    merge_ok = dk.merge_status(dev) == 0
     avg_s = e0.elapsed_time(e1) * 1e-3 / (rounds * nl)
     avg_bytes = sum(bytes_alg) / len(bytes_alg)
     achieved = avg_bytes / avg_s / 1e9
-    return {"bound": "hbm", "kernel": "decode_fused_kernel", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(workload, int(avg_bytes)),
+    n_splits = dk.plan_internal_splits(B * cfg.kv_heads, model.attn[0].page_table.shape[-1] * model.attn[0].page_size,
+                                       None)
+    one_kernel = B * cfg.kv_heads * n_splits <= dk._cus(dev.index)
+    traffic, traffic_src = pmc_traffic(workload, int(avg_bytes))
+    return {"bound": "hbm",
+            "kernel": "decode_fused_kernel (K/V streaming + in-launch split merge: the whole of reference a2)"
+                      if one_kernel else "decode_fused_kernel + decode_stage2_kernel (reference a2)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+            "splits": n_splits, "launches_per_layer": 1 if one_kernel else 2, "merge_included": True,
+            "merge_status_ok": merge_ok,
             "timing": f"one HIP event pair on the launch stream around {rounds} queued replays of a HIP graph holding "
-                      f"{nl} back-to-back launches (one per layer's cache), divided by {rounds * nl}; includes the "
-                      f"inter-launch dispatch gap"}
+                      f"the product's decode-attention call of all {nl} layers back to back (each on its own cache), "
+                      f"divided by {rounds * nl}; includes the inter-launch dispatch gap"}
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
@@ -168,28 +174,35 @@ def copy_bandwidth_gbs(dev, nbytes=1 << 30, rounds=5):
 
 
 def pmc_traffic(workload, alg_bytes):
-    """HBM bytes per launch from the PMC counters.  Counters cannot be read from inside the benchmark, so this
-    returns the figure of the committed rocprofv3 --pmc passes over THIS command (profiles/*_pmc.json,
-    FETCH_SIZE doubled per the gfx950 rule, + WRITE_SIZE), only when it was taken on the same workload and the
-    algorithmic bytes agree within 2 %; otherwise null."""
+    """(HBM bytes per launch, where the figure comes from).  Counters cannot be read from inside the benchmark; the
+    figure is taken from the newest committed `profiles/*_bench_pmc.json`, which tools/collect_profiles.sh writes from
+    separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md, + WRITE_SIZE) OVER
+    THIS COMMAND - and only if that file says it profiled bench.py on the same workload and its algorithmic bytes agree
+    within 2 %.  Anything else returns null with the reason."""
     try:
-        path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_bench_pmc.json"))[-1]
-        d = json.load(open(os.path.join(ROOT, "profiles", path)))
+        names = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_bench_pmc.json"))
+        if not names:
+            return None, "no profiles/*_bench_pmc.json"
+        d = json.load(open(os.path.join(ROOT, "profiles", names[-1])))
+        if "bench.py" not in d.get("command", ""):
+            return None, f"profiles/{names[-1]} was not taken over bench.py"
         if d.get("workload") != workload:
-            return None
-        k = d["kernels"]["cvllm::decode_fused_kernel<cvllm::BF16, 128, 4, 4, 4, 4>"]
+            return None, f"profiles/{names[-1]} is for workload {d.get('workload')}"
+        k = next(v for n, v in d["kernels"].items() if "decode_fused_kernel" in n)
         if abs(d["algorithmic_bytes_per_launch"] - alg_bytes) > 0.02 * alg_bytes:
-            return None
-        return int(k["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+            return None, f"profiles/{names[-1]}: algorithmic bytes differ"
+        return int(k["hbm_bytes_per_launch"]), f"profiles/{names[-1]} ({d['command']})"
+    except Exception as exc:  # noqa: BLE001
+        return None, f"unreadable: {type(exc).__name__}"
 
 
-def cpu_baseline(budget_s=20.0):
-    """The hot path on the host cores with the CPU oracle (kind 'port'): per-layer prefill attention +
-    Compactor scoring + joint selection for one 2048-token sequence at the Llama-3-8B head shape, then
-    decode-attention steps over the retained cache; reported as tokens/s of the attention path for a
-    32-layer stack (no GEMMs: the oracle restates only the path)."""
+def cpu_baseline(budget_s=25.0):
+    """The hot path on the host cores with the CPU oracle (kind 'port'), on BASELINE.json configs[0] (C1: HQ 32 / HKV 8 /
+    D 128 / page 128, ONE 4 096-token sequence, dense attention, fp16 like the reference's test shapes): one layer's
+    prefill attention + cache write, then decode-attention steps over the 4 096-row cache, all timed; tokens/s of the
+    attention path for a 32-layer stack = (4096 + new) / (32 * (t_prefill + new * t_decode)).  No GEMMs: the oracle
+    restates only the path.  The 32 K workload of the metric is NOT timed on the CPU: `extrapolated_32k` scales the
+    measured times by the operation counts (prefill x 64, decode x 8 at 50 % retention) and is labelled as such."""
     from oracle import ref_cpu as O
 
     try:
@@ -198,56 +211,52 @@ def cpu_baseline(budget_s=20.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))  # a 1-GPU box's CPU share is 16 cores; more threads than cores only thrash
     torch.set_num_threads(cores)
-    HQ, HKV, D, PS, Lp, layers = 32, 8, 128, 128, 1024, 32
+    HQ, HKV, D, PS, Lp, layers, new = 32, 8, 128, 128, 4096, 32, 256
     g = torch.Generator().manual_seed(1234)
-    q = torch.randn(Lp, HQ, D, generator=g).to(torch.bfloat16)
-    k = torch.randn(Lp, HKV, D, generator=g).to(torch.bfloat16)
-    v = torch.randn(Lp, HKV, D, generator=g).to(torch.bfloat16)
-    PHI = (torch.randn(D, 48, generator=g) / 48 ** 0.5).to(torch.bfloat16)
+    q = torch.randn(Lp, HQ, D, generator=g).to(torch.float16)
+    k = torch.randn(Lp, HKV, D, generator=g).to(torch.float16)
+    v = torch.randn(Lp, HKV, D, generator=g).to(torch.float16)
+    P = Lp // PS + 1
     cu = torch.tensor([0, Lp], dtype=torch.int32)
-    lens0 = torch.zeros(1, HKV, dtype=torch.int32)
+    lens = torch.zeros(1, HKV, dtype=torch.int32)
     bm = torch.ones(1, dtype=torch.int32)
-    pt = torch.arange(2 * HKV * (Lp // PS), dtype=torch.int32).view(2, HKV, Lp // PS)
-    kc = torch.zeros(2 * HKV * Lp, D, dtype=torch.bfloat16)
+    pt = torch.arange(2 * HKV * P, dtype=torch.int32).view(2, HKV, P)
+    kc = torch.zeros(2 * HKV * P * PS, D, dtype=torch.float16)
     vc = torch.zeros_like(kc)
     t0 = time.perf_counter()
-    O.prefill_attention(q, k, v, kc, vc, lens0, pt, bm, cu, HKV, PS)
-    pre = O.leverage_scores(k, [Lp], PHI, normalize=True, chunk_size=512)
-    sc = O.compactor_post_scores(q, k, cu, [Lp], pre, [16], [64])
-    retain = torch.tensor([O.retain_count(0.5, Lp, 16, 64, HKV)])
-    kept, new_lens = O.retained_sets(sc, cu, retain, lens0, bm, PS, True)
-    O.compact_store(k, v, kept, cu, lens0, pt, bm, kc, vc, PS)
+    O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS)
+    O.store_all_kv(k, v, cu, kc, vc, pt, lens, bm, PS)
     t_prefill = time.perf_counter() - t0
-    q1 = torch.randn(1, HQ, D, generator=g).to(torch.bfloat16)
+    q1 = torch.randn(1, HQ, D, generator=g).to(torch.float16)
     nd, t1 = 0, time.perf_counter()
-    while nd < 8 and time.perf_counter() - t0 < budget_s:
-        O.decode_attention(q1, kc, vc, new_lens, pt, bm, HKV, PS)
+    while nd < 16 and time.perf_counter() - t0 < budget_s:
+        O.decode_attention(q1, kc, vc, lens, pt, bm, HKV, PS)
         nd += 1
     t_dec = (time.perf_counter() - t1) / max(nd, 1)
-    new = 16
     tok_s = (Lp + new) / (layers * (t_prefill + new * t_dec))
     # the same prefill-attention call on ONE thread (SURVEY 8d asks for both), only if the budget allows
     t_one = None
-    if time.perf_counter() - t0 < budget_s:
+    if time.perf_counter() - t0 + 8 * t_prefill < budget_s + 20:
         torch.set_num_threads(1)
         t2 = time.perf_counter()
-        O.prefill_attention(q, k, v, kc, vc, lens0, pt, bm, cu, HKV, PS)
+        O.prefill_attention(q, k, v, kc, vc, torch.zeros_like(lens), pt, bm, cu, HKV, PS)
         t_one = time.perf_counter() - t2
         torch.set_num_threads(cores)
-        t3 = time.perf_counter()
-        O.prefill_attention(q, k, v, kc, vc, lens0, pt, bm, cu, HKV, PS)
-        t_all = time.perf_counter() - t3
     try:
         cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         cpu_model = "unknown"
+    ext = (32768 + new) / (layers * (64 * t_prefill + new * 4 * t_dec))  # S^2 prefill; decode over 16 K kept rows
     return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (torch fp32, {cores} threads) of the attention path only: 1 layer timed "
-                      f"(prefill attention + Compactor scoring + select/compact {t_prefill:.2f} s for {Lp} tokens; "
-                      f"decode attention {t_dec * 1e3:.1f} ms/token over the 50% cache), scaled to {layers} layers "
-                      f"and {new} new tokens; HQ=32 HKV=8 D=128 bf16; host CPU {cpu_model}, {avail} cores visible"
-                      + ("" if t_one is None else f"; prefill attention alone: {t_one:.2f} s on 1 thread vs "
-                                                  f"{t_all:.2f} s on {cores}")}
+            "workload": "C1 (BASELINE.json configs[0]): HQ=32 HKV=8 D=128 page=128, one 4096-token sequence, dense, fp16",
+            "extrapolated_32k": round(ext, 2),
+            "sample": f"CPU oracle (torch fp32, {cores} threads) of the attention path only, C1 timed in full for ONE "
+                      f"layer: prefill attention + cache write {t_prefill:.2f} s for {Lp} tokens, decode attention "
+                      f"{t_dec * 1e3:.1f} ms/token over the {Lp}-row cache ({nd} steps timed); value = ({Lp}+{new}) tokens "
+                      f"/ ({layers} layers x (prefill + {new} decode steps)); extrapolated_32k is NOT measured: the same "
+                      f"times scaled by operation count to the metric's 32768-token / 50 %-retention workload; host CPU "
+                      f"{cpu_model}, {avail} cores visible"
+                      + ("" if t_one is None else f"; prefill attention alone on 1 thread: {t_one:.2f} s")}
 
 
 def main():

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvllm_hip.so")
+LIB_PATH = os.environ.get("CVLLM_LIB_PATH") or os.path.join(_HERE, "libcvllm_hip.so")  # override: A/B builds
 
 _lib = None
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "cvllm_decode_attn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "cvllm_decode_append_attn": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I,
                                       _I, _F, _I, _I, _I, _P]),
+    "cvllm_decode_merge_status": (_I, [_P, _P]),
     "cvllm_num_splits": (_I, [_I, _I, _I, _I]),
     "cvllm_store_decode_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvllm_store_all_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

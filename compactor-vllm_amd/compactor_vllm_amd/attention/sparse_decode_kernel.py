@@ -16,29 +16,61 @@ from .. import _lib
 # MI355X: 256 CUs.  The ring kernel keeps ~128 KiB of LDS per workgroup, i.e. one workgroup per CU, and a CU
 # streams at most ~24 GB/s, so the plan is one workgroup per CU; each streams a contiguous run of rows of
 # one (batch, kv-head).
-_TARGET_WORKGROUPS = 256
+_TARGET_WORKGROUPS = 256  # MI355X; replaced by the device's CU count on first use (_cus)
 _MIN_ROWS_PER_SPLIT = 256
 _MAX_INTERNAL_SPLITS = 128
 
 _workspaces: dict = {}
+_retired: list = []  # outgrown workspaces: a HIP graph captured earlier may still hold their address
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Persistent per-(device, stream) scratch so decode stays graph-capture safe (no allocation inside the
-    captured region after the first, un-captured, warm-up call).  ZERO-initialised: its first 64 KiB hold the
-    split-merge ticket counters, which the kernel leaves at zero after every launch."""
+    """Persistent per-(device, stream) scratch so decode stays graph-capture safe (no allocation inside a captured
+    region as long as an un-captured call of at least that size ran on the same stream before).
+
+    ZERO-initialised, and every completed call leaves it all zeros again: the in-launch split merge uses it as
+    mailboxes in which 0 means "not written yet" (csrc/decode_attn.hip).  A buffer that has to grow is replaced, never
+    freed, because a captured graph replays with the address it was captured with."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(max(nbytes, 4 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _retired.append(buf)
+        buf = torch.zeros(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
+
+
+def merge_status(device: torch.device | None = None) -> int:
+    """Health check of the in-launch split merge for the current stream's workspace (synchronises the stream):
+    0 = fine; 1 = some call gave up waiting for a sibling split (its output rows hold NaN) - the workspace is then
+    re-zeroed here so that later calls start clean."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None:
+        return 0
+    st = int(_lib.lib().cvllm_decode_merge_status(buf.data_ptr(), _lib.stream()))
+    if st < 0:
+        _lib.check(st, "cvllm_decode_merge_status")
+    if st:
+        buf.zero_()
+    return st
+
+
+# MI355X: the in-launch merge needs the whole grid resident (one ring workgroup per CU), so the split count is the
+# largest that keeps batch * kv-heads * splits within the chip's CUs
+@functools.lru_cache(maxsize=None)
+def _cus(device_index: int) -> int:
+    global _TARGET_WORKGROUPS
+    _TARGET_WORKGROUPS = int(torch.cuda.get_device_properties(device_index).multi_processor_count)
+    return _TARGET_WORKGROUPS
 
 
 def plan_internal_splits(n_bh: int, max_len_bound: int, key_split: int | None) -> int:
     """Number of key splits the HIP kernel uses.  Depends only on host integers (batch, heads,
     the page-table width bound, the caller's key_split hint) so the launch is capture safe."""
-    want = max(1, -(-_TARGET_WORKGROUPS // max(n_bh, 1)))
+    want = max(1, _TARGET_WORKGROUPS // max(n_bh, 1))
     cap = max(1, max_len_bound // _MIN_ROWS_PER_SPLIT)
     s = min(want, cap, _MAX_INTERNAL_SPLITS)
     if key_split:
@@ -90,6 +122,7 @@ def head_sparse_decode_attention(
     seq_lens_bh = _lib.i32(seq_lens_bh)
     batch_mapping = _lib.i32(batch_mapping)
     page_table = _lib.i32(global_page_table)
+    _cus(q.device.index)
     n_splits = plan_internal_splits(B * HKV, n_lp * PAGE_SIZE, key_split)
 
     L = _lib.lib()
@@ -136,6 +169,7 @@ def fused_decode_step(
     assert batch_mapping.dtype == torch.int32 and page_table.is_contiguous() and page_table.dtype == torch.int32
     n_lp = page_table.shape[-1]
     sm_scale = 1 / math.sqrt(D) if sm_scale is None else sm_scale
+    _cus(q.device.index)
     n_splits = plan_internal_splits(B * HKV, n_lp * PAGE_SIZE, key_split)
     L = _lib.lib()
     out = torch.empty_like(q)

@@ -280,15 +280,50 @@ CVLLM_VMWAIT(0) CVLLM_VMWAIT(8) CVLLM_VMWAIT(12) CVLLM_VMWAIT(16) CVLLM_VMWAIT(2
 // at the phase boundaries of decode_fused_kernel.  Not compiled into libcvllm_hip.so.
 #ifdef CVLLM_DEC_TS
 __device__ unsigned long long g_dec_ts[16];
+__device__ unsigned long long g_dec_rt[1024 * 16];  // [workgroup][stamp]: s_memrealtime (100 MHz, one clock for all CUs)
 #define DEC_TS(i)                                                                    \
   do {                                                                               \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_ts[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define DEC_RT(i)                                                                                      \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_dec_rt[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define DEC_TS(i) \
   do {            \
   } while (0)
+#define DEC_RT(i) \
+  do {            \
+  } while (0)
 #endif
+
+// wave-wide all-reduces without LDS round trips: DPP inside the rows of 16 lanes, v_readlane across the four rows
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));
+  const int i = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float wave_allreduce_sum_fixed(float v) {  // the same tree on every call: reproducible bits
+  v = group_allreduce_sum<16>(v);
+  const int i = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it would make every wave
+// wait for its in-flight write-through (sc1) mailbox stores - about a microsecond each time in the merge tail.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int DEC_PGREGS = 8;       // page ids cached in registers: 8 x 64 pages
 constexpr int DEC_MAX_SPLITS = 256;
@@ -301,16 +336,18 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     const int* __restrict__ page_table, const uint16_t* __restrict__ key_new, const uint16_t* __restrict__ val_new,
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int HKV, int PS, int NLP, int S, float scale,
     int lens_by_row, int reserved, int64_t sk_b, int64_t sk_h, int64_t sv_b, int64_t sv_h,
-    uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse) {
+    uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
+    unsigned* __restrict__ merge_ws, unsigned* __restrict__ err_word, int mode) {
   // hipcc fetches kernel arguments lazily, one dependent s_load + wait in front of each first use (four round trips
   // in this kernel's prologue); naming them all here puts every fetch into one clause.
   asm volatile("" ::"s"(vc), "s"(HKV), "s"(PS), "s"(NLP), "s"(S), "s"(scale), "s"(lens_by_row), "s"(reserved));
-  asm volatile("" ::"s"(sk_b), "s"(sk_h), "s"(sv_b), "s"(sv_h), "s"(out), "s"(part_o), "s"(part_lse));
+  asm volatile("" ::"s"(sk_b), "s"(sk_h), "s"(sv_b), "s"(sv_h), "s"(out), "s"(part_o), "s"(part_lse), "s"(merge_ws),
+               "s"(err_word), "s"(mode));
   DEC_TS(0);
+  DEC_RT(0);
   constexpr int LPR = D / 8;
   constexpr int RPL = 64 / LPR;
   constexpr int UR = RPL * NL;
-  constexpr int ROUND = UR * NW;
   constexpr int UNIT_BYTES = 2 * NL * 1024;  // K loads then V loads
   constexpr int P = R - 1;                   // units in flight ahead of the one being reduced
   constexpr int NT_AUX = 2;                  // non-temporal: K/V are read once per step
@@ -371,24 +408,35 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
   const int L = (key_new != nullptr && bt == reserved) ? 0 : L_old + (append ? 1 : 0);
   DEC_TS(2);
 
-  int per = (L + S - 1) / S;
-  per = (per + ROUND - 1) / ROUND * ROUND;
-  const int start = s * per;
-  const int end = min(start + per, L);
+  // rows are dealt to the S splits in whole units (UR rows, the granule of one wave's load): split s gets units
+  // [s*U/S, (s+1)*U/S), so every split is within one unit of every other and no workgroup idles
+  const int U = (L + UR - 1) / UR;
+  const int start = (int)(((long long)s * U) / S) * UR;
+  const int end = min((int)(((long long)(s + 1) * U) / S) * UR, L);
   const bool empty = start >= end;
   const bool owns_new = append && !empty && L_old >= start && L_old < end;
 
   float* po = part_o + ((size_t)(b * S + s) * HQ + h * G) * D;
   float* pl = part_lse + (size_t)(b * S + s) * HQ + h * G;
 
+  // what this split hands to the merge: an UN-normalised partial (M, den, num[]) of the thread's OPT output dims
+  constexpr int NE = G * D;  // outputs of one (b, kv-head)
+  constexpr int OPT = (NE >= NW * 64) ? NE / (NW * 64) : 1;
+  static_assert(NE % OPT == 0 && D % OPT == 0, "output pass tiling");
+  const bool owner = tid * OPT < NE;  // this thread owns OPT consecutive dims of ONE head
+  const int g_t = (tid * OPT) / D, d0 = (tid * OPT) % D;
+  float pM = -INFINITY, pden = 0.f, pnum[OPT];
+#pragma unroll
+  for (int o = 0; o < OPT; ++o) pnum[o] = 0.f;
+
   if (!empty) {
     const int lp0 = start / PS;
+    int pg_win = 0;  // first page of the register window, relative to lp0 (window reloads: splits longer than 512 pages)
     if (!pg_abs) {
-      const int nlp = (end - 1) / PS - lp0 + 1;  // <= 64 * DEC_PGREGS (checked on the host)
 #pragma unroll
       for (int j = 0; j < DEC_PGREGS; ++j) {
         const int i = lane + 64 * j;
-        pgreg[j] = i < nlp ? pt[lp0 + i] : 0;
+        pgreg[j] = lp0 + i < NLP ? pt[lp0 + i] : 0;
       }
     }
     const int pg_bias = pg_abs ? lp0 : 0;  // page_of() takes a page index relative to the split
@@ -402,6 +450,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     asm volatile("" : "+v"(vnew.x), "+v"(vnew.y), "+v"(vnew.z), "+v"(vnew.w));
 
     DEC_TS(3);
+    DEC_RT(1);
     float m[G], l[G], acc[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -417,8 +466,8 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     const uint32_t lane_off = lane * 16;
 
-    auto page_of = [&](int lpi_rel) {
-      const int lpi = lpi_rel + pg_bias;
+    auto page_of = [&](int lpi_rel) {  // lpi_rel inside the register window
+      const int lpi = lpi_rel + pg_bias - pg_win;
       int pg = __builtin_amdgcn_readlane(pgreg[0], lpi & 63);
 #pragma unroll
       for (int j = 1; j < DEC_PGREGS; ++j)
@@ -428,7 +477,21 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
 
     auto issue = [&](int j) {  // wave-local unit j -> ring slot j % R
       const int row0 = start + (wave + j * NW) * UR;
-      const int pg = page_of(row0 / PS - lp0);
+      const int lpi_rel = row0 / PS - lp0;
+      if (!pg_abs && lpi_rel - pg_win >= 64 * DEC_PGREGS) {
+        // rare (a split longer than 512 pages = 64 K rows at PS 128): the wave walks its rows in order, so the window
+        // only ever moves forward.  The reload is an ordinary load: it drains the ring once (hipcc's vmcnt(0) at the
+        // asm below, INSIDE this block, so the loop's other iterations keep their counted waits).
+        pg_win = lpi_rel;
+#pragma unroll
+        for (int jj = 0; jj < DEC_PGREGS; ++jj) {
+          const int i = lp0 + pg_win + lane + 64 * jj;
+          pgreg[jj] = i < NLP ? pt[i] : 0;
+        }
+#pragma unroll
+        for (int jj = 0; jj < DEC_PGREGS; ++jj) asm volatile("" : "+v"(pgreg[jj]));
+      }
+      const int pg = page_of(lpi_rel);
       const size_t base = ((size_t)pg * PS + (row0 % PS) + c) * D + dl * 8;
       char* slot = ring + (j % R) * UNIT_BYTES;
 #pragma unroll
@@ -447,6 +510,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     for (int j = 0; j < P; ++j)
       if (j < njw) issue(j);
     DEC_TS(4);
+    DEC_RT(2);
 
     for (int j = 0; j < njw; ++j) {
       if (j + P < njw) {
@@ -537,9 +601,11 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     }
 
     DEC_TS(5);
+    DEC_RT(3);
     if (owns_new) {  // write the appended row into the paged cache (one 16-lane group owns it)
       const int u = (L_old - start) / UR;  // unit of the new row
       if ((u % NW) == wave && c == ((L_old - start) % UR) % RPL) {
+        // the owning wave issued this unit last, so its page is inside the wave's register window
         const int pg = page_of(L_old / PS - lp0);
         const size_t dst = ((size_t)pg * PS + L_old % PS) * D + dl * 8;
         *reinterpret_cast<uint4*>(kc + dst) = knew;
@@ -554,7 +620,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     // by the output pass below, which needed LDS and a barrier for the cross-wave merge anyway.
     constexpr int NPART = NW * RPL;
     constexpr int ST_ML = RPL * G * D * 4;  // byte offset of the (m, l) pairs inside a wave's staging area
-    static_assert(ST_ML + RPL * G * 8 <= R * UNIT_BYTES, "staging area must fit the wave's ring");
+    static_assert(ST_ML + RPL * G * 8 <= R * UNIT_BYTES - 512, "staging area must fit the wave's ring (minus scratch)");
     {
       char* st = ring;  // all of this wave's DMA has landed and been read (tail iterations drained vmcnt / lgkmcnt)
 #pragma unroll
@@ -568,61 +634,253 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     DEC_TS(6);
     __syncthreads();
     DEC_TS(7);
+    DEC_RT(4);
     // output pass: a thread owns OPT consecutive dims of ONE head, so the NPART weights exp(m_p - M) are computed once
     // per thread (wave-uniform head -> broadcast LDS reads)
-    constexpr int OPT = (G * D >= NW * 64) ? (G * D) / (NW * 64) : 1;
-    static_assert((G * D) % OPT == 0 && D % OPT == 0, "output pass tiling");
-    if (tid * OPT < G * D) {
-      const int g = (tid * OPT) / D, d0 = (tid * OPT) % D;
+    if (owner) {
       float2 ml[NPART];
       float M = -INFINITY;
 #pragma unroll
       for (int p_ = 0; p_ < NPART; ++p_) {
         const char* st = smem + (p_ / RPL) * (R * UNIT_BYTES);
-        ml[p_] = *reinterpret_cast<const float2*>(st + ST_ML + ((p_ % RPL) * G + g) * 8);
+        ml[p_] = *reinterpret_cast<const float2*>(st + ST_ML + ((p_ % RPL) * G + g_t) * 8);
         M = fmaxf(M, ml[p_].x);  // finite: group 0 of wave 0 always owns a valid row
       }
-      float num[OPT], den = 0.f;
-#pragma unroll
-      for (int o = 0; o < OPT; ++o) num[o] = 0.f;
+      float den = 0.f;
 #pragma unroll
       for (int p_ = 0; p_ < NPART; ++p_) {
         const char* st = smem + (p_ / RPL) * (R * UNIT_BYTES);
         const float a = __expf(ml[p_].x - M);
         den = fmaf(a, ml[p_].y, den);
-        const float* ap = reinterpret_cast<const float*>(st + (((p_ % RPL) * G + g) * D + d0) * 4);
+        const float* ap = reinterpret_cast<const float*>(st + (((p_ % RPL) * G + g_t) * D + d0) * 4);
 #pragma unroll
-        for (int o = 0; o < OPT; ++o) num[o] = fmaf(a, ap[o], num[o]);
+        for (int o = 0; o < OPT; ++o) pnum[o] = fmaf(a, ap[o], pnum[o]);
       }
-      const float inv = 1.f / den;
-#pragma unroll
-      for (int o = 0; o < OPT; ++o) {
-        const float ov = num[o] * inv;
-        if (S == 1) {
-          out[((size_t)b * HQ + h * G + g) * D + d0 + o] = to16<T>(ov);
-        } else {
-          po[g * D + d0 + o] = ov;
-        }
-      }
-      if (S != 1 && d0 == 0) pl[g] = M + __logf(den);
-    }
-  } else {  // empty split (covers L == 0 and RESERVED rows)
-    if (S == 1) {
-      for (int i = tid; i < G * D; i += NW * 64) out[((size_t)b * HQ + h * G) * D + i] = 0;
-    } else if (tid < G) {
-      pl[tid] = -INFINITY;
+      pM = M;
+      pden = den;
     }
   }
 
-  // S == 1: this is the only workgroup of (b,h) and it has consumed L_old -> publish the new length here.
-  // S > 1: the merge kernel (stream-ordered after every stage-1 workgroup) publishes it.
-  if (S == 1 && append && tid == 0) seq_lens[lidx] = L_old + 1;
+  if (S == 1) {
+    // the only workgroup of (b,h): normalise and store; it has consumed L_old -> publish the new length here
+    if (owner) {
+      const float inv = pden > 0.f ? 1.f / pden : 0.f;  // empty (L == 0, RESERVED rows): zeros
+#pragma unroll
+      for (int o = 0; o < OPT; ++o) out[((size_t)b * HQ + h * G + g_t) * D + d0 + o] = to16<T>(pnum[o] * inv);
+    }
+    if (append && tid == 0) seq_lens[lidx] = L_old + 1;
+  } else if (mode != 2) {
+    // two-kernel path: normalised fp32 partial + lse for decode_stage2_kernel (which also publishes the length)
+    if (!empty) {
+      if (owner) {
+        const float inv = 1.f / pden;
+#pragma unroll
+        for (int o = 0; o < OPT; ++o) po[g_t * D + d0 + o] = pnum[o] * inv;
+        if (d0 == 0) pl[g_t] = pM + __logf(pden);
+      }
+    } else if (tid < G) {
+      pl[tid] = -INFINITY;
+    }
+  } else {
+    // ---- in-launch merge of the S splits of (b, kv-head) ----------------------------------------------------------
+    // All S workgroups of a (b, kv-head) are co-resident (the host only selects this mode when the whole grid fits the
+    // chip's CUs).  Workgroup s_m merges output elements [s_m*EPW, (s_m+1)*EPW) of the NE = G*D outputs: every split
+    // sends it that slice of its un-normalised numerator and the (M, den) of the heads the slice touches, and it
+    // combines them with the LSE rule (reference :391-435) in a FIXED order (bit-reproducible).
+    // Hand-off (CDNA guide, Guideline 16 form R2 "the data is the flag"): every word is written exactly once per
+    // launch with an agent-scope (sc1, write-through) store, carries its own validity (fp32 bits inverted, 0 = not
+    // yet written), is polled with agent-scope (L1-bypassing) loads, and is reset to 0 by its ONE reader once read,
+    // so the workspace is all zeros again when the launch ends: no fences, no counters, no epoch.
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    auto st_w = [](unsigned* p, unsigned v) {
+      __hip_atomic_store((gu32*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto ld_w = [](const unsigned* p) {
+      return __hip_atomic_load((gu32*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto enc = [](float x) {
+      const unsigned u = ~__float_as_uint(x);
+      return u ? u : 1u;  // 0 is "not written"; the one pattern that maps to it (a NaN) becomes another NaN
+    };
+    auto dec = [](unsigned u) { return __uint_as_float(~u); };
+
+    int EPW = (NE + S - 1) / S;
+    EPW += EPW & 1;
+    const int NM = (NE + EPW - 1) / EPW;      // workgroups that own a slice
+    const int NHB = (EPW + D - 1) / D + 1;    // heads one slice can touch
+    const int MLSZ = NHB * S * 2;
+    const int AREA = MLSZ + S * EPW;          // dwords of one merger's private mailbox: [NHB][S][2] (M, den) | [S][EPW]
+    unsigned* grp = merge_ws + (size_t)bh * S * AREA;
+    const float rEPW = 1.0f / (float)EPW;
+    auto div_epw = [&](int e) {  // e / EPW for e < 2^16 without the integer-division sequence
+      int qd = (int)((float)e * rEPW);
+      qd -= (qd * EPW > e) ? 1 : 0;
+      qd += ((qd + 1) * EPW <= e) ? 1 : 0;
+      return qd;
+    };
+
+    constexpr int SCR = NW * R * UNIT_BYTES - 512;  // tail of wave NW-1's ring: never part of a staging area
+    float* sMl = reinterpret_cast<float*>(smem + SCR);          // [G][2] this split's (M, den) per head
+    int* sFail = reinterpret_cast<int*>(smem + SCR + 256);
+    if (owner && d0 == 0) {
+      sMl[2 * g_t] = pM;
+      sMl[2 * g_t + 1] = pden;
+    }
+    if (tid == 0) *sFail = 0;
+    if (owner) {
+#pragma unroll
+      for (int o = 0; o < OPT; ++o) {
+        const int e = tid * OPT + o;
+        const int sm = div_epw(e);
+        st_w(grp + (size_t)sm * AREA + MLSZ + s * EPW + (e - sm * EPW), enc(pnum[o]));
+      }
+    }
+    DEC_RT(5);
+    lds_barrier();  // sMl visible; every read of the staging areas is done -> LDS below is free
+    for (int sm = tid; sm < NM; sm += NW * 64) {
+      const int e0 = sm * EPW, e1 = min(NE, e0 + EPW);
+      const int glo = e0 / D, ghi = (e1 - 1) / D;
+      for (int g = glo; g <= ghi; ++g) {
+        unsigned* p = grp + (size_t)sm * AREA + ((g - glo) * S + s) * 2;
+        st_w(p, enc(sMl[2 * g]));
+        st_w(p + 1, enc(sMl[2 * g + 1]));
+      }
+    }
+
+    DEC_RT(6);
+    if (s < NM) {
+      constexpr int MLCAP = 544;  // nh * S <= G + 2 S (1 + 1/D) <= 528
+      float* sM = reinterpret_cast<float*>(smem);
+      float* sDen = sM + MLCAP;
+      float* sMx = sDen + MLCAP;  // [nh <= 16] max over the splits
+      float* sV = sMx + 16;       // [S][EPW] (S*EPW <= NE + 512) numerators
+      const int e0 = s * EPW, e1 = min(NE, e0 + EPW);
+      const int glo = e0 / D, nh = (e1 - 1) / D - glo + 1;
+      const int nml = nh * S * 2;
+      const int nel = e1 - e0;  // elements of this slice that exist (< EPW only in the last slice)
+      unsigned* my = grp + (size_t)s * AREA;
+      // item mapping without divisions: a thread walks a [S][EPW] grid in steps of (SXW, ELW), ELW a power of two
+      int ELW = 2;
+      while (ELW < EPW && ELW < NW * 64) ELW <<= 1;
+      const int lg = 31 - __builtin_clz(ELW);
+      const int SXW = (NW * 64) >> lg;
+      const int el_l = tid & (ELW - 1), sx_l = tid >> lg;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      for (;;) {  // poll: every pass re-reads this thread's words; a word is valid once it is non-zero
+        bool ok = true;
+        for (int j = tid; j < nml; j += NW * 64) {
+          const unsigned u = ld_w(my + j);
+          ok &= u != 0u;
+          ((j & 1) ? sDen : sM)[j >> 1] = dec(u);
+        }
+        for (int el0 = 0; el0 < nel; el0 += ELW)
+          for (int sx0 = 0; sx0 < S; sx0 += SXW) {
+            const int el = el0 + el_l, sx = sx0 + sx_l;
+            if (el < nel && sx < S) {
+              const unsigned u = ld_w(my + MLSZ + sx * EPW + el);
+              ok &= u != 0u;
+              sV[sx * EPW + el] = dec(u);
+            }
+          }
+        if (__all(ok)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {  // 0.5 s: a sibling split never arrived
+          if (lane == 0) {
+            *sFail = 1;
+            __hip_atomic_fetch_or((gu32*)(uintptr_t)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      DEC_RT(7);
+      // hand the mailbox back zeroed (every word this thread polled) NOW: the write-through stores then complete under
+      // the merge arithmetic below instead of holding up the end of the kernel (the barriers below are LDS-only)
+      for (int j = tid; j < nml; j += NW * 64) st_w(my + j, 0u);
+      for (int el0 = 0; el0 < nel; el0 += ELW)
+        for (int sx0 = 0; sx0 < S; sx0 += SXW) {
+          const int el = el0 + el_l, sx = sx0 + sx_l;
+          if (el < nel && sx < S) st_w(my + MLSZ + sx * EPW + el, 0u);
+        }
+      lds_barrier();
+      DEC_RT(10);
+      // LSE rule (reference :391-435): w_s = exp(M_s - max_s M_s); empty splits carry M = -inf and weigh nothing.
+      // Everything below avoids serial LDS chains (one wave per SIMD: ~130 cycles per dependent LDS read): maxima and
+      // the denominator by wave reductions that every wave does for itself (no barrier), numerators by all threads.
+      float* sP = sV + (NE + 2 * DEC_MAX_SPLITS);  // [nel][SXW] partial sums of the weighted numerators
+      float* sDs = sMx;                            // [nh] sum_s w_s * den_s
+      float part[2] = {0.f, 0.f};                  // nel <= 2 * ELW whenever ELW < 256; else one el per pass (below)
+      for (int gi = 0; gi < nh; ++gi) {
+        float mv = -INFINITY;
+        for (int sx = lane; sx < S; sx += 64) mv = fmaxf(mv, sM[gi * S + sx]);
+        const float mx = wave_allreduce_max(mv);  // wave-uniform
+        float dv = 0.f;
+        for (int sx = lane; sx < S; sx += 64) {
+          const float mm = sM[gi * S + sx];
+          dv += (mm == -INFINITY) ? 0.f : __expf(mm - mx) * sDen[gi * S + sx];
+        }
+        dv = wave_allreduce_sum_fixed(dv);  // fixed tree: bit-reproducible
+        if (tid == 0) sDs[gi] = dv;
+        int pi = 0;
+        for (int el0 = 0; el0 < nel; el0 += ELW, ++pi) {
+          const int el = el0 + el_l;
+          float acc_p = 0.f;
+          if (el < nel && (e0 + el) / D - glo == gi) {
+            for (int sx = sx_l; sx < S; sx += SXW) {  // ascending splits: fixed order
+              const float mm = sM[gi * S + sx];
+              acc_p += (mm == -INFINITY) ? 0.f : __expf(mm - mx) * sV[sx * EPW + el];
+            }
+            if (ELW < NW * 64) part[pi & 1] = acc_p;
+            else sP[el] = acc_p;  // SXW == 1: the partial is the sum
+          }
+        }
+      }
+      if (ELW < NW * 64) {
+        int pi = 0;
+        for (int el0 = 0; el0 < nel; el0 += ELW, ++pi) {
+          const int el = el0 + el_l;
+          if (el < nel) sP[el * SXW + sx_l] = part[pi & 1];
+        }
+      }
+      lds_barrier();
+      DEC_RT(12);
+      const bool failed = *sFail != 0;
+      if (SXW == 16) {
+        // 16 partials per output element sit in 16 consecutive lanes: one LDS read + a row reduction (fixed tree)
+        for (int t = tid; t < nel * 16; t += NW * 64) {
+          const int el = t >> 4;
+          const float a = group_allreduce_sum<16>(sP[t]);
+          if ((t & 15) == 0) {
+            const float ds = sDs[(e0 + el) / D - glo];
+            float o = ds > 0.f ? a / ds : 0.f;  // every split empty (L == 0, RESERVED rows): zeros
+            if (failed) o = __uint_as_float(0x7fc00000u);
+            out[((size_t)b * HQ + h * G) * D + e0 + el] = to16<T>(o);
+          }
+        }
+      } else {
+        for (int el = tid; el < nel; el += NW * 64) {
+          float a = 0.f;
+          for (int k = 0; k < SXW; ++k) a += sP[el * SXW + k];  // fixed order
+          const float ds = sDs[(e0 + el) / D - glo];
+          float o = ds > 0.f ? a / ds : 0.f;
+          if (failed) o = __uint_as_float(0x7fc00000u);
+          out[((size_t)b * HQ + h * G) * D + e0 + el] = to16<T>(o);
+        }
+      }
+      DEC_RT(8);
+      // split 0's mailbox has been filled by ALL S splits, i.e. every one of them has read L_old: publish the new length
+      if (s == 0 && append && tid == 0) seq_lens[lidx] = L_old + 1;
+    }
+  }
   DEC_TS(8);
+  DEC_RT(9);
 }
 #ifdef CVLLM_DEC_TS
 }  // namespace cvllm
 extern "C" void cvllm_debug_read_decode_ts(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_dec_ts), sizeof(unsigned long long) * 16);
+}
+extern "C" void cvllm_debug_read_decode_rt(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_dec_rt), sizeof(unsigned long long) * 1024 * 16);
 }
 namespace cvllm {
 #endif
@@ -636,11 +894,12 @@ constexpr size_t ring_smem_bytes() {
 // 4 waves per (b, hq): every wave first reads all S lse values (<= 256), then waves take the splits
 // round-robin with independent, unrolled loads; the four partial sums meet in LDS.
 template <typename T, int D>
-__global__ __launch_bounds__(256) void decode_stage2_kernel(const float* __restrict__ part_o,
-                                                           const float* __restrict__ part_lse,
+__global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ part_o, float* __restrict__ part_lse,
                                                            uint16_t* __restrict__ out, int HQ, int S,
                                                            int* __restrict__ seq_lens, const int* __restrict__ bmap,
                                                            int G, int append, int lens_by_row, int reserved) {
+  // The partials live in the same workspace the in-launch merge uses as zero-means-empty mailboxes, so this kernel
+  // hands the workspace back the way it got it: every word it consumed is reset to zero.
   constexpr int VPT = D / 64;  // values per lane
   __shared__ float s_acc[4][D];
   const int bhq = blockIdx.x;
@@ -683,63 +942,117 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(const float* __restr
         if ((s >> 6) == j) w[i] = __shfl(lse[j], s & 63, 64);
       if (s >= S) w[i] = 0.f;
       const int sc = s < S ? s : 0;  // clamp: always a valid address; weight 0 discards it
-      const float* po = part_o + ((size_t)(b * S + sc) * HQ + hq) * D + lane * VPT;
+      float* po = part_o + ((size_t)(b * S + sc) * HQ + hq) * D + lane * VPT;
 #pragma unroll
       for (int j = 0; j < VPT; ++j) v[i][j] = po[j];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < VPT; ++j) acc[j] += (w[i] != 0.f) ? w[i] * v[i][j] : 0.f;  // never 0 * garbage
+      const int s = s0 + wave + 4 * i;
+      if (s < S) {  // this wave is the only reader of split s's row: hand it back zeroed
+        float* po = part_o + ((size_t)(b * S + s) * HQ + hq) * D + lane * VPT;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) po[j] = 0.f;
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < VPT; ++j) s_acc[wave][lane * VPT + j] = acc[j];
-  __syncthreads();
+  __syncthreads();  // also: every wave has read the lse words
   if (tid < D) {
     const float inv = den > 0.f ? 1.f / den : 0.f;
     const float v = (s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid]) * inv;
     out[((size_t)b * HQ + hq) * D + tid] = to16<T>(v);
   }
+  for (int s = tid; s < S; s += 256) part_lse[(size_t)(b * S + s) * HQ + hq] = 0.f;
 }
 
-static hipEvent_t g_evt_start = nullptr, g_evt_stop = nullptr;  // bench.py roofline leg
-static int g_skip_stage2 = 0;                                        // bench.py roofline leg: stage-1 launches only
+constexpr size_t DEC_WS_HEADER = 256;  // bytes: word 0 = in-launch merge error flag; the rest reserved (zero)
 
 struct DecodeArgs {
   const void *q, *key_new, *val_new;
   void *kc, *vc, *out;
   int* seq_lens;
   const int *page_table, *bmap;
-  float* ws;
+  char* ws;
+  size_t ws_bytes;
   int64_t sk_b, sk_h, sv_b, sv_h;
   int B, HKV, PS, NLP, S, lens_by_row, reserved;
   float scale;
   hipStream_t st;
 };
 
+// dwords of the in-launch merge mailboxes for (B*HKV groups, S splits, NE = G*D outputs per group); mirrors the
+// kernel's EPW / NHB / AREA arithmetic
+static size_t merge_mailbox_dwords(int groups, int S, int NE, int D) {
+  int EPW = (NE + S - 1) / S;
+  EPW += EPW & 1;
+  const int NHB = (EPW + D - 1) / D + 1;
+  return (size_t)groups * S * ((size_t)NHB * S * 2 + (size_t)S * EPW);
+}
 
+// CUs of the current device (cached per device): the in-launch merge needs every workgroup of the grid resident
+static int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+// CVLLM_DECODE_MERGE=two-kernel forces the separate merge kernel (A/B measurements, tests of that path)
+static bool merge_in_launch_allowed() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CVLLM_DECODE_MERGE");
+    v = (e && (e[0] == 't' || e[0] == '2')) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <typename K>
+static void set_dyn_lds_once(K kern, int bytes) {  // per device: the attribute lives on the device's code object
+  static bool done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !done[dev]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev >= 0 && dev < 64) done[dev] = true;
+  }
+}
 
 template <typename T, int D, int G>
 static int launch_fused(const DecodeArgs& a) {
   constexpr int NW = 4, NL = 4, R = 4;
   const int HQ = a.HKV * G;
-  float* part_o = a.ws;
-  float* part_lse = part_o + (size_t)a.B * a.S * HQ * D;
   constexpr size_t smem = ring_smem_bytes<D, G, NW, NL, R>();
   static_assert(smem <= 160 * 1024, "LDS budget");
   auto kern = decode_fused_kernel<T, D, G, NW, NL, R>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
+  set_dyn_lds_once(kern, (int)smem);
+  const int grid = a.B * a.HKV * a.S;
+  // mode 0: one split, direct output.  mode 2: splits merged inside the launch (needs the whole grid co-resident: one
+  // workgroup per CU).  mode 1: fp32 partials + decode_stage2_kernel (oversubscribed grids, or forced by the environment).
+  int mode = 0;
+  if (a.S > 1) {
+    const bool fits = a.ws_bytes >= DEC_WS_HEADER + 4 * merge_mailbox_dwords(a.B * a.HKV, a.S, G * D, D);
+    mode = (merge_in_launch_allowed() && grid <= device_cus() && fits) ? 2 : 1;
   }
-  if (g_evt_start) (void)hipEventRecord(g_evt_start, a.st);
-  hipLaunchKernelGGL(kern, dim3(a.B * a.HKV * a.S), dim3(NW * 64), smem, a.st, (const uint16_t*)a.q, a.bmap, a.seq_lens,
+  char* body = a.ws ? a.ws + DEC_WS_HEADER : nullptr;  // no workspace is needed (or read) with one split
+  unsigned* err_word = reinterpret_cast<unsigned*>(a.ws);
+  float* part_o = reinterpret_cast<float*>(body);
+  float* part_lse = mode == 1 ? part_o + (size_t)a.B * a.S * HQ * D : nullptr;
+  unsigned* mailboxes = reinterpret_cast<unsigned*>(body);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, a.st, (const uint16_t*)a.q, a.bmap, a.seq_lens,
                      a.page_table, (const uint16_t*)a.key_new, (const uint16_t*)a.val_new, (uint16_t*)a.kc,
                      (uint16_t*)a.vc, a.HKV, a.PS, a.NLP, a.S, a.scale, a.lens_by_row, a.reserved, a.sk_b, a.sk_h,
-                     a.sv_b, a.sv_h, (uint16_t*)a.out, part_o, part_lse);
-  if (g_evt_stop) (void)hipEventRecord(g_evt_stop, a.st);
-  if (a.S > 1 && !g_skip_stage2)
+                     a.sv_b, a.sv_h, (uint16_t*)a.out, part_o, part_lse, mailboxes, err_word, mode);
+  if (mode == 1)
     hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(a.B * HQ), dim3(256), 0, a.st, part_o, part_lse,
                        (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, a.key_new != nullptr ? 1 : 0, a.lens_by_row,
                        a.reserved);
@@ -750,7 +1063,7 @@ static int launch_fused(const DecodeArgs& a) {
 template <typename T, int D, int G>
 static int launch_fallback(const DecodeArgs& a) {
   const int HQ = a.HKV * G;
-  float* part_o = a.ws;
+  float* part_o = reinterpret_cast<float*>(a.ws + DEC_WS_HEADER);
   float* part_lse = part_o + (size_t)a.B * a.S * HQ * D;
   dim3 grid(a.B * a.HKV * a.S), block(DEC_NW * 64);
   if (a.S == 1) {
@@ -800,7 +1113,11 @@ using namespace cvllm;
 
 extern "C" size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits) {
   if (B <= 0 || HQ <= 0 || D <= 0 || n_splits <= 0) return 0;
-  return ((size_t)B * n_splits * HQ * D + (size_t)B * n_splits * HQ) * sizeof(float);  // fp32 partials | fp32 lse
+  // header | max(fp32 partials + lse of the two-kernel path, in-launch merge mailboxes for any G in {1,2,4,8})
+  const size_t S = (size_t)n_splits;
+  const size_t two_kernel = ((size_t)B * S * HQ * D + (size_t)B * S * HQ) * sizeof(float);
+  const size_t mailboxes = (size_t)B * HQ * S * ((size_t)D + 8 * S + 8) * sizeof(unsigned);  // bound of merge_mailbox_dwords
+  return DEC_WS_HEADER + (two_kernel > mailboxes ? two_kernel : mailboxes);
 }
 
 static int decode_common(DecodeArgs a, int HQ, int D, int dtype, size_t workspace_bytes) {
@@ -809,9 +1126,8 @@ static int decode_common(DecodeArgs a, int HQ, int D, int dtype, size_t workspac
   if (HQ % a.HKV != 0 || a.S > DEC_MAX_SPLITS) return CVLLM_ERR_SHAPE;
   // a unit of (64/(D/8))*4 rows must not straddle a page; the reference requires PAGE_SIZE % 32 == 0 (:80)
   if (a.PS <= 0 || a.PS % 32 != 0) return CVLLM_ERR_SHAPE;
-  // the ring kernel keeps page ids in 8 VGPRs (512 pages): the whole row, or else one split's window
-  if (a.NLP > 64 * DEC_PGREGS && (a.NLP + a.S - 1) / a.S + 1 > 64 * DEC_PGREGS) return CVLLM_ERR_SHAPE;
   if (a.S > 1 && (!a.ws || workspace_bytes < cvllm_decode_workspace_bytes(a.B, HQ, D, a.S))) return CVLLM_ERR_WORKSPACE;
+  a.ws_bytes = workspace_bytes;
   if (a.key_new && D > 128) return CVLLM_ERR_SHAPE;  // fused append exists in the ring kernel only
   const int G = HQ / a.HKV;
   if (dtype == CVLLM_F16) return dispatch_d<F16>(D, G, a);
@@ -827,7 +1143,7 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
   DecodeArgs a{};
   a.q = q; a.kc = (void*)k_cache; a.vc = (void*)v_cache; a.out = out;
   a.seq_lens = (int*)seq_lens_bh;  // read-only without an appended row
-  a.page_table = page_table; a.bmap = batch_mapping; a.ws = (float*)workspace;
+  a.page_table = page_table; a.bmap = batch_mapping; a.ws = (char*)workspace;
   a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 0;
   a.reserved = -1; a.scale = sm_scale; a.st = (hipStream_t)stream;
   return decode_common(a, HQ, D, dtype, workspace_bytes);
@@ -846,22 +1162,24 @@ extern "C" int cvllm_decode_append_attn(const void* q, const void* key, const vo
   if ((sk_b % 8) || (sk_h % 8) || (sv_b % 8) || (sv_h % 8)) return CVLLM_ERR_SHAPE;
   DecodeArgs a{};
   a.q = q; a.key_new = key; a.val_new = value; a.kc = k_cache; a.vc = v_cache; a.out = out;
-  a.seq_lens = bh_seq_lens; a.page_table = page_table; a.bmap = batch_mapping; a.ws = (float*)workspace;
+  a.seq_lens = bh_seq_lens; a.page_table = page_table; a.bmap = batch_mapping; a.ws = (char*)workspace;
   a.sk_b = sk_b; a.sk_h = sk_h; a.sv_b = sv_b; a.sv_h = sv_h;
   a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 1;
   a.reserved = reserved_batch; a.scale = sm_scale; a.st = (hipStream_t)stream;
   return decode_common(a, HQ, D, dtype, workspace_bytes);
 }
 
-// bench.py: HIP events recorded immediately before / after the decode kernel launch on the launch stream
-extern "C" void cvllm_debug_set_decode_events(void* start, void* stop) {
-  g_evt_start = (hipEvent_t)start;
-  g_evt_stop = (hipEvent_t)stop;
+// Status of the in-launch split merge of the calls that used `workspace` so far: 0 = fine, 1 = a merging workgroup
+// gave up waiting for a sibling split (outputs of that call hold NaN; re-zero the workspace before reusing it).
+// Synchronises the stream: a health check for tests and engines, not part of the data path.
+extern "C" int cvllm_decode_merge_status(const void* workspace, cvllm_stream_t stream) {
+  if (!workspace) return CVLLM_ERR_ARG;
+  unsigned w = 0;
+  if (hipMemcpyAsync(&w, workspace, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return CVLLM_ERR_LAUNCH;
+  return (int)(w & 1u);
 }
-
-// bench.py: launch only decode_fused_kernel (no merge kernel; the output is then NOT an attention result) so that a
-// run of back-to-back launches times that kernel alone
-extern "C" void cvllm_debug_set_decode_stage2(int enabled) { g_skip_stage2 = enabled ? 0 : 1; }
 
 // Host restatement of num_splits_heuristic (cv/attention/sparse_decode_kernel.py:169-192).
 extern "C" int cvllm_num_splits(int total_mblocks, int max_seq_len, int num_sms, int max_splits) {

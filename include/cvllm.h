@@ -46,9 +46,17 @@ const char* cvllm_error_string(int status);
  *          :246-388 _varkv_stage1_groupM, :391-435 _varkv_stage2_reduce.
  * q[B,HQ,D] contiguous; k_cache/v_cache [cache_rows,D]; seq_lens_bh[B,HKV] (lengths INCLUDING the
  * current token); page_table[*,HKV,n_logical_pages_max]; batch_mapping[B]; out[B,HQ,D].
- * n_splits is the number of key splits the kernel uses internally (>=1); workspace holds the
- * fp32 partials.  Rows with L==0 produce zeros (reference: uninitialised, quirk Q6).        */
+ * n_splits is the number of key splits the kernel uses internally (>=1).  With n_splits > 1 `workspace`
+ * (cvllm_decode_workspace_bytes) is required and MUST BE ZERO when first handed to the library; every completed
+ * call leaves it zero again.  When B*HKV*n_splits fits the device's CUs the splits are merged inside the one
+ * launch (workgroups exchange partials through self-validating mailbox words in the workspace; all of them are
+ * resident, every wait is bounded); otherwise fp32 partials are merged by a second kernel.  One workspace serves one
+ * stream at a time.  Rows with L==0 produce zeros (reference: uninitialised, quirk Q6).
+ * Any n_logical_pages_max is accepted (page ids are windowed through registers 512 at a time).              */
 size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits);
+/* health check (synchronises `stream`): 0 fine, 1 = an in-launch merge timed out since the workspace was zeroed
+ * (that call's outputs are NaN; re-zero the workspace), negative = error                                     */
+int cvllm_decode_merge_status(const void* workspace, cvllm_stream_t stream);
 int cvllm_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
                       const int32_t* seq_lens_bh, const int32_t* page_table,
                       const int32_t* batch_mapping, void* workspace, size_t workspace_bytes,

@@ -177,3 +177,10 @@ def test_prefill_chunked_equals_one_shot(dev, split):
     two = torch.cat([o1, o2])
     d = (one.float() - two.float()).abs().max()
     assert torch.allclose(one.float(), two.float(), rtol=1e-6, atol=tol(dtype)), d
+    # oracle leg: the CPU restatement's ONE-SHOT dense causal attention is what both must equal
+    dummy = torch.zeros(PS, D, dtype=dtype)
+    ref = O.prefill_attention(q.cpu(), k.cpu(), v.cpu(), dummy, dummy, torch.zeros(1, HKV, dtype=torch.int32),
+                              torch.zeros(2, HKV, 1, dtype=torch.int32), torch.ones(1, dtype=torch.int32),
+                              torch.tensor([0, N], dtype=torch.int32), HKV, PS, 1.0 / math.sqrt(D)).float()
+    assert torch.allclose(two.cpu().float(), ref, rtol=1e-6, atol=tol(dtype)), (two.cpu().float() - ref).abs().max()
+    assert torch.allclose(one.cpu().float(), ref, rtol=1e-6, atol=tol(dtype))

@@ -43,19 +43,27 @@ def test_leverage_golden(dev, name):
                                       chunk_size=c["chunk_size"]).cpu()
     assert out.dtype == k.dtype and out.shape == c["out"].shape
     chunks = O.split_into_chunks(lens, c["chunk_size"]) if c["chunk_size"] > 0 else lens
+    # chunks of >= 96 rows: SURVEY P3 bar vs the reference (0.1 z-scored, 0.01 raw; measured need 0.078 / 0.0032);
+    # shorter tails are "parity unpinned" upstream (tests/test_oracle_golden.py::test_leverage_short_tails_are_unpinned)
     mask = torch.zeros(out.shape[0], dtype=torch.bool)
     s = 0
-    for L in chunks:  # chunks with < 2*sketch rows: z-scores of a (near) constant = rounding noise upstream
-        if not c["normalize"] or L >= 96:
+    for L in chunks:
+        if L >= 96:
             mask[s : s + L] = True
         s += L
-    atol_ref = 0.3 if c["normalize"] else 0.08
-    assert torch.allclose(out.float()[mask], c["out"].float()[mask], rtol=0, atol=atol_ref)
+    atol_ref = 0.1 if c["normalize"] else 0.01
+    d = (out.float()[mask] - c["out"].float()[mask]).abs().max()
+    assert torch.allclose(out.float()[mask], c["out"].float()[mask], rtol=0, atol=atol_ref), float(d)
+    # against the fp32 oracle of the same closed form EVERY chunk counts, tails included: a few output ulps
     orc = O.leverage_scores(k, lens, PHI, normalize=bool(c["normalize"]), chunk_size=c["chunk_size"])
     ulp = 2.0 ** -7 if k.dtype == torch.bfloat16 else 2.0 ** -10
     atol_o = (6 * ulp * 5) if c["normalize"] else 4 * ulp  # a few output ulps (|z| <= ~5, scores <= ~1)
-    assert torch.allclose(out.float()[mask], orc.float()[mask], rtol=0, atol=atol_o), \
-        (out.float()[mask] - orc.float()[mask]).abs().max()
+    if c["normalize"]:  # a tail's z-scores amplify one-ulp differences of the rounded raw scores by 1/std
+        assert torch.allclose(out.float()[mask], orc.float()[mask], rtol=0, atol=atol_o), \
+            (out.float()[mask] - orc.float()[mask]).abs().max()
+        assert torch.isfinite(out.float()).all()
+    else:
+        assert torch.allclose(out.float(), orc.float(), rtol=0, atol=atol_o), (out.float() - orc.float()).abs().max()
 
 
 def test_leverage_unnormalised_fp32_accuracy(dev):

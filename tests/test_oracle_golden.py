@@ -78,6 +78,22 @@ def test_select_oracle(name):
         assert torch.equal(a[finite], r[finite])
 
 
+# Leverage-score tolerances vs the reference's own 16-bit output (measured need on the committed vectors:
+# 0.078 z-scored / 0.0032 raw on chunks of >= 96 rows).  Chunks with fewer than 2 * 48 rows are the documented
+# exception, see test_leverage_short_tails_are_unpinned.
+LEV_ATOL_Z, LEV_ATOL_RAW, LEV_MIN_ROWS = 0.1, 0.01, 96
+
+
+def _chunk_mask(chunks, pred):
+    mask = torch.zeros(sum(chunks), dtype=torch.bool)
+    s = 0
+    for L in chunks:
+        if pred(L):
+            mask[s : s + L] = True
+        s += L
+    return mask
+
+
 @pytest.mark.parametrize("name", list_cases("leverage_"))
 def test_leverage_oracle(name):
     c = load_case(name)
@@ -86,19 +102,45 @@ def test_leverage_oracle(name):
     ref = c["out"].float()
     dt = c["k"].dtype
     chunks = O.split_into_chunks(lens, c["chunk_size"]) if c["chunk_size"] > 0 else lens
-    # chunks with fewer than 2*sketch rows have (near-)constant leverage ~1: their z-scores are pure rounding
-    # noise in the reference (1/std of a constant) -> excluded from the normalised comparison.
-    mask = torch.zeros(out.shape[0], dtype=torch.bool)
-    s = 0
-    for L in chunks:
-        if not c["normalize"] or L >= 96:
-            mask[s : s + L] = True
-        s += L
     if dt == torch.float32:
-        atol = 1e-4
-    else:
-        atol = 0.3 if c["normalize"] else 0.08  # the reference's own 16-bit Gram/SVD noise
-    assert torch.allclose(out.float()[mask], ref[mask], rtol=0, atol=atol)
+        assert torch.allclose(out.float(), ref, rtol=0, atol=1e-4)  # every chunk, tails included
+        return
+    mask = _chunk_mask(chunks, lambda L: L >= LEV_MIN_ROWS)
+    atol = LEV_ATOL_Z if c["normalize"] else LEV_ATOL_RAW
+    d = (out.float()[mask] - ref[mask]).abs().max()
+    assert torch.allclose(out.float()[mask], ref[mask], rtol=0, atol=atol), float(d)
+
+
+@pytest.mark.parametrize("name", [n for n in list_cases("leverage_") if "f32" not in n])
+def test_leverage_short_tails_are_unpinned(name):
+    """What happens on chunks with fewer than 2 * sketch (= 96) rows, stated as a test.  With L < ~2r rows the centred
+    sketch has rank < r + something and every leverage score sits near 1 - reg/(sigma^2 + reg): the RAW scores of the
+    reference (16-bit Gram + SVD) still agree with the fp32 closed form to <= 0.08, but their spread is of the order
+    of the 16-bit rounding, so the reference's z-scores of such a chunk are (x - mean) / std of rounding noise: the
+    committed vectors differ from the fp32 evaluation by up to 0.23 (bf16, 76 / 88 rows) and 7.0 (f16, 44 rows <
+    48 sketch columns).  PARITY UNPINNED for z-scored tails; what IS guaranteed and checked: the oracle's tail is the
+    exact z-score of its own rounded raw scores (zero mean, unit variance), finite, and the raw scores stay within
+    0.08.  Such tails lie inside `protected_last = 64` tokens or next to them in practice."""
+    c = load_case(name)
+    lens = c["context_lens"].tolist()
+    chunks = O.split_into_chunks(lens, c["chunk_size"]) if c["chunk_size"] > 0 else lens
+    tails = _chunk_mask(chunks, lambda L: L < LEV_MIN_ROWS)
+    assert tails.any(), "fixture without a short tail"
+    out = O.leverage_scores(c["k"], lens, c["PHI"], normalize=bool(c["normalize"]), chunk_size=c["chunk_size"]).float()
+    ref = c["out"].float()
+    assert torch.isfinite(out[tails]).all() and torch.isfinite(ref[tails]).all()
+    if not c["normalize"]:
+        assert torch.allclose(out[tails], ref[tails], rtol=0, atol=0.08)
+        return
+    s = 0
+    worst = 0.0
+    for L in chunks:
+        if L < LEV_MIN_ROWS:
+            for t in (out[s : s + L], ref[s : s + L]):  # each side is a standardisation of its own raw scores
+                assert abs(float(t.mean())) < 0.05 and abs(float(t.std(unbiased=False)) - 1.0) < 0.05
+            worst = max(worst, float((out[s : s + L] - ref[s : s + L]).abs().max()))
+        s += L
+    assert worst > LEV_ATOL_Z  # documents that the tight bar does NOT hold here (if it ever does, tighten the mask)
 
 
 @pytest.mark.parametrize("name", list_cases("chunkattn_"))
