@@ -55,7 +55,7 @@ def hip_events(n):
     return hip, evs
 
 
-def roofline_decode_attn(model, state, workload, rounds=5):
+def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
     """Achieved HBM GB/s of decode attention AS THE REFERENCE DEFINES IT (a2 = stage 1 + split merge,
     cv/attention/sparse_decode_kernel.py:246-435) on the REAL post-prefill cache of every layer (distinct memory per
     layer, 2.2 GB per pass => cold L2 / Infinity Cache, like inside a decode step).
@@ -89,15 +89,19 @@ def roofline_decode_attn(model, state, workload, rounds=5):
 
     one_pass()  # warm-up (workspace allocation)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        one_pass()
-    graph.replay()
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_pass()
+        replay = graph.replay
+    else:  # --no-graph (the rocprofv3 --pmc passes): the same launches issued eagerly
+        replay = one_pass
+    replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(rounds):
-        graph.replay()
+        replay()
     e1.record()
     torch.cuda.synchronize()
     merge_ok = dk.merge_status(dev) == 0
@@ -116,8 +120,9 @@ def roofline_decode_attn(model, state, workload, rounds=5):
             "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
             "splits": n_splits, "launches_per_layer": 1 if one_kernel else 2, "merge_included": True,
             "merge_status_ok": merge_ok,
-            "timing": f"one HIP event pair on the launch stream around {rounds} queued replays of a HIP graph holding "
-                      f"the product's decode-attention call of all {nl} layers back to back (each on its own cache), "
+            "timing": f"one HIP event pair on the launch stream around {rounds} queued "
+                      + ("replays of a HIP graph holding" if use_graph else "eager passes of")
+                      + f" the product's decode-attention call of all {nl} layers back to back (each on its own cache), "
                       f"divided by {rounds * nl}; includes the inter-launch dispatch gap"}
 
 
@@ -369,7 +374,7 @@ def main():
     if rank == 0:
         state = {}
         step(state)  # one more generate whose cache stays allocated: the roofline leg runs on the real cache
-        result["roofline"] = roofline_decode_attn(model, state, args.workload)
+        result["roofline"] = roofline_decode_attn(model, state, args.workload, use_graph=not args.no_graph)
         copy_bw = copy_bandwidth_gbs(dev)
         result["roofline"]["copy_bw"] = round(copy_bw, 1)  # measured device copy rate: the practical HBM roof
         result["roofline"]["frac_of_copy_bw"] = round(result["roofline"]["achieved"] / copy_bw, 4)
@@ -400,7 +405,7 @@ def main():
                     torch.cuda.synchronize()
                     dts.append(time.perf_counter() - t1)
                 dt = min(dts)
-                mr = roofline_decode_attn(model, mstate, "-")
+                mr = roofline_decode_attn(model, mstate, "-", use_graph=not args.no_graph)
                 for bi in mstate["rows"]:
                     model.cache.free_batch(bi)
                 result["multi_sequence"] = {

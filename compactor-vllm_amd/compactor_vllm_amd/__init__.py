@@ -2,13 +2,17 @@
 
 Module paths mirror the reference package `compactor_vllm` for everything on the path:
 `attention.*`, `compression.*`, `kv_cache.*`, `layers.attention`, `utils.{context,helpers}`, `config.*`.
-The engine (`LLM`, scheduler, model runner, models) is out of scope: the reference's own
-engine keeps calling these modules; `bench.py` carries the thin driver used for measurement.
+The engine loop (`LLM`, scheduler, KV-cache manager, model runner) lives in `core.*` and drives any
+model object that follows the small protocol of `core.model_runner`; weights, tokenizers and the model zoo stay out of
+scope - `bench.py` supplies a random-weight model of the benchmark's shape.
 """
 from .compression import BatchCompressionParams, CompressionMethod, SequenceCompressionParams
 from .config import AttentionBackend, LLMConfig, SamplingParams
+from .core.llm_engine import LLM, LLMEngine
 
 __all__ = [
+    "LLM",
+    "LLMEngine",
     "LLMConfig",
     "SamplingParams",
     "AttentionBackend",

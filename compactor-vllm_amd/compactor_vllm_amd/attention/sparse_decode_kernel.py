@@ -155,6 +155,7 @@ def fused_decode_step(
     sm_scale: float = None,
     key_split: int = None,
     reserved_batch: int = 0,
+    max_len_hint: int = 0,
 ):
     """decode_store_kv + head_sparse_decode_attention + length write-back of the reference's decode branch
     (layers/attention.py:127-160) in one C-ABI call that works directly on the layer's length table."""
@@ -170,7 +171,8 @@ def fused_decode_step(
     n_lp = page_table.shape[-1]
     sm_scale = 1 / math.sqrt(D) if sm_scale is None else sm_scale
     _cus(q.device.index)
-    n_splits = plan_internal_splits(B * HKV, n_lp * PAGE_SIZE, key_split)
+    bound = n_lp * PAGE_SIZE if not max_len_hint else min(n_lp * PAGE_SIZE, int(max_len_hint))  # tuning only
+    n_splits = plan_internal_splits(B * HKV, bound, key_split)
     L = _lib.lib()
     out = torch.empty_like(q)
     ws, ws_bytes = None, 0

@@ -1,0 +1,233 @@
+"""Execution loop of one engine process (one process per GPU; whole sequences per process).
+
+What the reference's `ModelRunner` does for one rank (`compactor_vllm/core/model_runner.py`): owns the KV-cache manager
+and the store stream (`:70-78`), runs packed prefills with the compression context installed (`:198-236`), keeps ONE
+continuously batched decode batch alive across prefill waves with the reference's stash / occupancy policy
+(`:266-338`), runs the decode loop with finished sequences dropped from the batch (`:391-470`), replays captured graphs
+keyed by (batch bucket, context bucket) with `RESERVED_BATCH` padding rows (`:472-555`).  Built differently:
+
+* the model is any object with `model(input_ids, positions) -> hidden`, `model.compute_logits(hidden) -> [B, vocab]`
+  (last token of every sequence during prefill) and the per-layer `Attention` modules (see
+  `memory_manager.attention_modules`); weights, tokenizer and tensor parallelism are out of scope;
+* positions, length limits and sequence ids of the decode batch live on the HOST (they are deterministic), so a decode
+  step costs no device->host round trip unless an EOS id is configured (the reference syncs on `masked_select` every
+  step); sampled tokens stay on the device until the loop hands control back;
+* HIP graphs are captured lazily, on first use of a bucket, with an all-`RESERVED_BATCH` mapping (the kernels skip such
+  rows), so capturing never needs free cache rows; buckets are powers of two in the batch and
+  {1K, 4K, 8K, 16K, 32K, 64K, 128K} in the context - the context bucket only bounds the decode kernel's split plan;
+* the store stream is joined before page reclamation reads the per-head lengths (hazard H2 of SURVEY section 3.1).
+
+Quirk kept (Q11): a sequence emits `max_new_tokens + 1` tokens - the one sampled from the prefill logits plus one per
+decode step while `position < prompt_len + max_new_tokens` (`:408-411`).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ..compression.compression_config import BatchCompressionParams
+from ..config.constants import RESERVED_BATCH
+from ..config.engine_config import LLMConfig
+from ..layers.sampler import Sampler
+from ..utils.arguments import (DecodeBatchArguments, DecodeBatchOutput, PrefillBatchArguments, build_prefill_args,
+                               make_phi)
+from ..utils.context import CompressionContext, reset_context, set_context
+from ..utils.sequence import Sequence
+from .memory_manager import KVCacheManager
+from .scheduler import Scheduler
+
+logger = logging.getLogger(__name__)
+
+CONTEXT_BUCKETS = (1024, 4096, 8192, 16384, 32768, 65536, 131072)
+
+
+class _GraphSlot:
+    __slots__ = ("graph", "input_ids", "positions", "batch_mapping", "logits")
+
+
+class ModelRunner:
+    def __init__(self, config: LLMConfig, model, device=None, *, num_pages: Optional[int] = None,
+                 max_batched_tokens: Optional[int] = None, seed: int = 42):
+        if config.tensor_parallel_size != 1:
+            raise NotImplementedError("one process per GPU with whole sequences per process; tensor parallelism is out "
+                                      "of scope (SURVEY section 2.2)")
+        self.config = config
+        self.model = model
+        self.device = torch.device(device if device is not None else
+                                   (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"))
+        self.on_gpu = self.device.type == "cuda"
+        self.enforce_eager = bool(config.enforce_eager) or not self.on_gpu
+        self.max_num_batches = int(config.max_num_seqs)
+        self.max_model_len = int(config.max_model_len)
+        self.kv_manager = KVCacheManager(config, self.device, num_pages=num_pages, max_batched_tokens=max_batched_tokens)
+        self.kv_manager.init_cache(model)
+        self.max_batched_tokens = self.kv_manager.max_batched_tokens
+        self.store_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.sampler = Sampler()
+        hf = config.hf_config
+        self.PHI = make_phi(self.kv_manager.head_dim, int(config.leverage_sketch_size), self.kv_manager.model_dtype,
+                            self.device, seed)
+        self.num_kv_heads = int(hf.num_key_value_heads)
+        self.captured_graphs: Dict[Tuple[int, int], _GraphSlot] = {}
+        self.last_scheduler: Optional[Scheduler] = None
+
+    # ------------------------------------------------------------------------------------------------ prefill
+    @torch.inference_mode()
+    def run_prefill(self, a: PrefillBatchArguments, batch_mapping: torch.Tensor) -> torch.Tensor:
+        assert a.B > 0 and a.N > 0
+        cc = CompressionContext(
+            compression_method=a.compression_method, compression_chunk_size=a.compression_chunk_size,
+            batch_tokens_to_retain=a.batch_tokens_to_retain, max_tokens_to_retain=a.max_tokens_to_retain,
+            context_lens=a.context_lens.tolist(), PHI=a.PHI, protected_first_tokens=a.protected_first,
+            protected_last_tokens=a.protected_last)
+        set_context(is_prefill=True, do_compression=a.do_compression, cu_seqlens_q=a.cu_seqlens_q,
+                    cu_seqlens_k=a.cu_seqlens_k, max_seqlen_q=a.max_seqlen_q, max_seqlen_k=a.max_seqlen_k,
+                    batch_mapping=batch_mapping, max_bh_len=0, compression_context=cc, STORE_STREAM=self.store_stream,
+                    attention_backend=self.config.attention_backend)
+        try:
+            return self.model.compute_logits(self.model(a.input_ids, a.positions))
+        finally:
+            reset_context()
+
+    def _join_store_stream(self) -> None:
+        if self.store_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.store_stream)
+
+    # ------------------------------------------------------------------------------------------------ generate
+    @torch.inference_mode()
+    def generate(self, all_sequences: List[Sequence], batch_compression_params: Optional[BatchCompressionParams] = None):
+        params = batch_compression_params if batch_compression_params is not None else BatchCompressionParams()
+        sched = Scheduler(all_sequences, self.kv_manager, use_tqdm=bool(self.config.show_progress_bar))
+        self.last_scheduler = sched
+        batch = DecodeBatchArguments()
+        pending_out: List[Tuple[torch.Tensor, List[int]]] = []  # (tokens on device, seq ids) not yet written back
+        try:
+            while not sched.is_finished():
+                seqs = sched.get_prefill_batch()
+                if seqs:
+                    ids = [s.seq_id for s in seqs]
+                    sched.add_running_sequence_ids(ids, update_status=True)
+                    args = build_prefill_args(seqs, params, self.num_kv_heads, self.PHI, self.device)
+                    max_ctx = args.max_new_tokens + args.context_lens.to(torch.int64)
+                    ok, rows = self.kv_manager.allocate_sequences(ids, max_ctx.tolist())
+                    if not ok:
+                        raise RuntimeError("failed to allocate pages for sequences")
+                    temps = torch.tensor([s.sampling_params.temperature for s in seqs], dtype=torch.float32,
+                                         device=self.device)
+                    logits = self.run_prefill(args, rows)
+                    tokens = self.sampler(logits, temps)
+                    pending_out.append((tokens, ids))
+                    # H2: the per-head lengths are written on the store stream
+                    self._join_store_stream()
+                    self.kv_manager.reclaim_pages(ids, args.max_new_tokens.tolist())
+                    occupancy = int((len(batch) + len(ids)) * 0.66) if sched.any_pending_sequences() else -1
+                    batch.update(rows, tokens, args.context_lens.to(torch.int64), max_ctx, args.seq_ids, temps, occupancy)
+                    if sched.can_prefill_another_batch():
+                        continue
+                elif len(batch) == 0:
+                    raise RuntimeError("a pending prompt does not fit the KV cache even with nothing else running")
+                else:
+                    # nothing fits right now: decode until at least one running sequence finishes and frees its pages
+                    batch.desired_batch_occupancy = len(batch) - 1
+                self._join_store_stream()
+                out, batch = self.run_decode_loop(batch, pending_out)
+                pending_out = []
+                finished = sched.get_finished_sequence_ids_from_unfinished(batch.seq_ids.tolist() if len(batch) else [])
+                sched.record_finished_sequence_ids(finished, update_status=True)
+                self.kv_manager.free_sequences(finished)
+                sched.update_sequences(out.output_tokens.tolist(), out.output_seq_ids.tolist())
+        finally:
+            sched.close()
+        return all_sequences
+
+    # ------------------------------------------------------------------------------------------------ decode loop
+    @torch.inference_mode()
+    def run_decode_loop(self, batch: DecodeBatchArguments, pending_out=None):
+        """Decode until the batch is empty or has shrunk to `desired_batch_occupancy`.  `positions`, `max_ctx_lens` and
+        `seq_ids` of the batch are host tensors; `token_ids`, `batch_mapping`, `temps` live on the device."""
+        eos = int(self.config.eos)
+        tok_chunks: List[torch.Tensor] = []
+        id_chunks: List[List[int]] = []
+        for toks, ids in (pending_out or []):
+            tok_chunks.append(toks)
+            id_chunks.append(list(ids))
+        pos_dev = batch.positions.to(self.device)
+        while True:
+            running = batch.positions < batch.max_ctx_lens  # host
+            if eos >= 0:
+                running &= batch.token_ids.cpu() != eos  # one round trip per step only when an EOS id is configured
+            if not bool(running.all()):
+                keep = running.nonzero().flatten()
+                batch.positions, batch.max_ctx_lens = batch.positions[keep], batch.max_ctx_lens[keep]
+                batch.seq_ids = batch.seq_ids[keep]
+                kd = keep.to(self.device)
+                batch.token_ids, batch.batch_mapping = batch.token_ids[kd], batch.batch_mapping[kd]
+                batch.temps, pos_dev = batch.temps[kd], pos_dev[kd]
+            n = len(batch)
+            if n == 0 or n <= batch.desired_batch_occupancy:
+                batch.num_stashed_batches = n
+                break
+            hint = int(batch.positions.max()) + 1
+            if self.enforce_eager:
+                # the same context buckets as the graphs: the split plan (hence the fp32 summation order) of a sequence
+                # then does not depend on which other sequences share its batch
+                set_context(is_prefill=False, do_compression=False, batch_mapping=batch.batch_mapping,
+                            decode_len_hint=self._bucket(n, hint)[1])
+                logits = self.model.compute_logits(self.model(batch.token_ids, pos_dev))
+            else:
+                logits = self.run_graph_decode(batch.token_ids, pos_dev, batch.batch_mapping, hint)
+            batch.token_ids = self.sampler(logits, batch.temps)
+            tok_chunks.append(batch.token_ids)
+            id_chunks.append(batch.seq_ids.tolist())
+            batch.positions = batch.positions + 1
+            pos_dev = pos_dev + 1
+        reset_context()
+        if tok_chunks:
+            out = DecodeBatchOutput(torch.cat(tok_chunks).cpu(), torch.tensor([i for c in id_chunks for i in c],
+                                                                              dtype=torch.int64))
+        else:
+            out = DecodeBatchOutput(torch.empty(0, dtype=torch.int64), torch.empty(0, dtype=torch.int64))
+        return out, batch
+
+    # ------------------------------------------------------------------------------------------------ graphs
+    def _bucket(self, n: int, hint: int) -> Tuple[int, int]:
+        bs = 1
+        while bs < n:
+            bs <<= 1
+        ctx = next((c for c in CONTEXT_BUCKETS if c >= hint), CONTEXT_BUCKETS[-1])
+        return bs, min(ctx, max(self.max_model_len, CONTEXT_BUCKETS[0]))
+
+    def capture_graph(self, bs: int, ctx_bucket: int) -> _GraphSlot:
+        """Capture one decode step for `bs` rows.  Every row maps to RESERVED_BATCH during the warm-up and the capture:
+        the kernels neither append nor read anything for such rows, so no cache rows are needed."""
+        dev = self.device
+        slot = _GraphSlot()
+        slot.input_ids = torch.zeros(bs, dtype=torch.int64, device=dev)
+        slot.positions = torch.zeros(bs, dtype=torch.int64, device=dev)
+        slot.batch_mapping = torch.full((bs,), RESERVED_BATCH, dtype=torch.int32, device=dev)
+        set_context(is_prefill=False, do_compression=False, batch_mapping=slot.batch_mapping, decode_len_hint=ctx_bucket)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up on the capture stream: lazy allocations (per-stream workspaces) happen here
+                self.model.compute_logits(self.model(slot.input_ids, slot.positions))
+            side.synchronize()
+            slot.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(slot.graph, stream=side):
+                slot.logits = self.model.compute_logits(self.model(slot.input_ids, slot.positions))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.captured_graphs[(bs, ctx_bucket)] = slot
+        return slot
+
+    def run_graph_decode(self, input_ids, positions, batch_mapping, hint: int) -> torch.Tensor:
+        n = input_ids.shape[0]
+        key = self._bucket(n, hint)
+        slot = self.captured_graphs.get(key) or self.capture_graph(*key)
+        slot.input_ids[:n] = input_ids
+        slot.positions[:n] = positions
+        slot.batch_mapping.fill_(RESERVED_BATCH)
+        slot.batch_mapping[:n] = batch_mapping
+        slot.graph.replay()
+        return slot.logits[:n]

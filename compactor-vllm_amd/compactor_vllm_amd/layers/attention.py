@@ -105,7 +105,7 @@ class Attention(nn.Module):
             assert self.k_cache is not None, "KV Cache must be initialized for decoding"
             return fused_decode_step(q, k, v, self.k_cache, self.v_cache, self.bh_seq_lens, self.page_table,
                                      batch_mapping, int(self.num_kv_heads), self.page_size, self.scale,
-                                     key_split=context.key_split)
+                                     key_split=context.key_split, max_len_hint=context.decode_len_hint)
         seq_lens = self._gathered_lengths(batch_mapping)
         if context.is_prefill:
             o = self._prefill(context, q, k, v, scores, seq_lens)

@@ -41,6 +41,9 @@ _CONTEXT_FIELDS = (
     ("STORE_STREAM", Any, None),                         # torch.cuda.Stream | None
     ("key_split", Optional[int], None),
     ("attention_backend", AttentionBackend, AttentionBackend.COMPACTOR_TRITON),
+    # extension (not in the reference): an upper bound of the longest cached sequence of a decode batch, 0 = unknown.
+    # Only tunes the decode kernel's split count (short contexts take fewer splits); never affects results.
+    ("decode_len_hint", int, 0),
 )
 
 
