@@ -55,6 +55,37 @@ def hip_events(n):
     return hip, evs
 
 
+@torch.inference_mode()
+def prefill_only(llm, prompts, bcp, ratio):
+    """Prefill (with scoring / eviction / reclamation exactly as `ModelRunner.generate` does it) and KEEP the sequences'
+    cache rows, for the roofline leg: returns {"bm": batch rows on the device, "ids": sequence ids to free}."""
+    from compactor_vllm_amd import SamplingParams, SequenceCompressionParams
+    from compactor_vllm_amd.utils.arguments import build_prefill_args
+    from compactor_vllm_amd.utils.sequence import Sequence
+
+    r = llm.master_model_runner
+    bms, ids_all = [], []
+    pending = [Sequence(p, sampling_params=SamplingParams(0.0, 8), compression_params=SequenceCompressionParams(ratio, 16, 64))
+               for p in prompts]
+    while pending:  # same packing rule as the scheduler: a prefill wave holds at most max_batched_tokens
+        wave, used = [], 0
+        while pending and (not wave or used + pending[0].prompt_len <= r.max_batched_tokens):
+            used += pending[0].prompt_len
+            wave.append(pending.pop(0))
+        a = build_prefill_args(wave, bcp, r.num_kv_heads, r.PHI, r.device)
+        ids = [s.seq_id for s in wave]
+        ok, rows = r.kv_manager.allocate_sequences(ids, (a.max_new_tokens + a.context_lens).tolist())
+        assert ok
+        r.run_prefill(a, rows)
+        r._join_store_stream()
+        r.kv_manager.reclaim_pages(ids, a.max_new_tokens.tolist())
+        bms.append(rows)
+        ids_all += ids
+    torch.cuda.synchronize()
+    return {"bm": torch.cat(bms), "ids": ids_all}
+
+
+@torch.inference_mode()  # like the engine: its graphs register RNG state as inference tensors
 def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
     """Achieved HBM GB/s of decode attention AS THE REFERENCE DEFINES IT (a2 = stage 1 + split merge,
     cv/attention/sparse_decode_kernel.py:246-435) on the REAL post-prefill cache of every layer (distinct memory per
@@ -129,6 +160,7 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 
 
+@torch.inference_mode()
 def roofline_prefill_attn(model, ctx, rounds=3):
     """Second roofline object: the prefill attention kernel (MFMA-bound) at the workload's context length on
     synthetic q/k/v of the model's head shape with an empty cache; causal FLOPs = 4 * S^2 * D * HQ / 2 per launch,
@@ -163,6 +195,7 @@ def roofline_prefill_attn(model, ctx, rounds=3):
             "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops_per_launch": flops}
 
 
+@torch.inference_mode()
 def copy_bandwidth_gbs(dev, nbytes=1 << 30, rounds=5):
     """Practical HBM roof next to the 8 TB/s spec: a device-to-device copy of 1 GiB (read + write =
     2 GiB moved) timed with events on the current stream."""
@@ -308,7 +341,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bench_shell as bs
-    from compactor_vllm_amd.compression import CompressionMethod
+    from compactor_vllm_amd import (LLM, BatchCompressionParams, CompressionMethod, LLMConfig, SamplingParams,
+                                    SequenceCompressionParams)
 
     shape, ctx, new, method_name, ratio = WORKLOADS[args.workload]
     ctx = args.ctx or ctx
@@ -321,12 +355,32 @@ def main():
     # batch looks like); the KV pool is sized for it up front, which does not change the 1-sequence timings
     MULTI = 4
     multi_leg = world == 1 and nseq == 1 and not args.no_multi_seq and args.workload != "tiny"
-    model = bs.ModelShell(cfg, dev, max_model_len=ctx + new, max_seqs=MULTI if multi_leg else nseq, seed=0)
+    max_seqs = MULTI if multi_leg else nseq
+    model = bs.ModelShell(cfg, dev, max_model_len=ctx + new, seed=0)
+    # The product's engine drives the shell model: scheduler, paged KV cache (pages for the FULL uncompressed length
+    # are reserved before prefill and reclaimed after compaction, like the reference), prefill with scoring + eviction
+    # on the store stream, continuous-batching decode on HIP graphs.  One packed prefill holds up to 256 K tokens;
+    # longer batches (C5) are prefilled sequence by sequence and decoded together (scheduler.py:65-108).
+    page = 128
+    conf = LLMConfig(model=cfg.name, max_num_seqs=max_seqs, max_model_len=ctx + new, hf_config=model.hf_config, eos=-1,
+                     kvcache_page_size=page, enforce_eager=args.no_graph, show_progress_bar=False)
+    llm = LLM(conf, model, device=dev, num_pages=max_seqs * cfg.kv_heads * (-(-(ctx + new) // page)) + 8,
+              max_batched_tokens=max(ctx, min(nseq * ctx, 262144)))
     g = torch.Generator().manual_seed(1 + rank)
-    prompts = [torch.randint(0, cfg.vocab, (ctx,), generator=g) for _ in range(nseq)]
+    prompts = [torch.randint(0, cfg.vocab, (ctx,), generator=g).tolist() for _ in range(nseq)]
+    # `new` tokens per sequence: the one sampled from the prefill logits + (new - 1) decode steps (quirk Q11 of the
+    # reference's loop: max_new_tokens counts decode steps)
+    sampling = SamplingParams(temperature=0.0, max_new_tokens=new - 1)
+    bcp = BatchCompressionParams(compression_method=method)
 
-    def step(keep=None):
-        return model.generate(prompts, new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
+    def run(ps):
+        out = llm.generate(ps, sampling, bcp, per_sequence_compression_params=[
+            SequenceCompressionParams(ratio, protected_first_tokens=16, protected_last_tokens=64) for _ in ps])
+        assert all(len(o) == new for o in out)
+        return out
+
+    def step():
+        return run(prompts)
 
     for _ in range(args.warmup):
         step()
@@ -366,14 +420,14 @@ def main():
         "config": {
             "workload": f"{args.workload}: {cfg.name} random weights, {ctx}-token prefill + {new} decode per sequence, "
                         f"{method_name} ratio {ratio} (protected 16/64, chunk 512), {nseq} sequence(s) per GPU, "
-                        f"store-stream overlapped scoring+eviction, HIP-graph decode",
+                        f"store-stream overlapped scoring+eviction, HIP-graph decode, driven by the product's engine "
+                        f"(LLM.generate: scheduler, paged KV cache, continuous batching)",
             "ctx": ctx, "new_tokens": new, "method": method_name, "ratio": ratio, "sequences_per_gpu": nseq,
             "parallelism": f"replicas x{world} (sequences sharded, no collectives)",
         },
     }
     if rank == 0:
-        state = {}
-        step(state)  # one more generate whose cache stays allocated: the roofline leg runs on the real cache
+        state = prefill_only(llm, prompts, bcp, ratio)  # a prefill whose cache stays allocated: the real cache
         result["roofline"] = roofline_decode_attn(model, state, args.workload, use_graph=not args.no_graph)
         copy_bw = copy_bandwidth_gbs(dev)
         result["roofline"]["copy_bw"] = round(copy_bw, 1)  # measured device copy rate: the practical HBM roof
@@ -382,32 +436,24 @@ def main():
             result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
         except Exception as exc:  # noqa: BLE001 - secondary object, see above
             result["roofline_prefill"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-        for bi in state["rows"]:
-            model.cache.free_batch(bi)
+        llm.master_model_runner.kv_manager.free_sequences(state["ids"])
         if multi_leg:
             # an extra leg must never cost the main line: anything going wrong here is reported, not raised
             try:
-                mp = prompts + [torch.randint(0, cfg.vocab, (ctx,), generator=g) for _ in range(MULTI - 1)]
-
-                def mstep(keep=None):
-                    return model.generate(mp, new, method, ratio, use_graph=not args.no_graph, keep_state=keep)
-
+                mp = prompts + [torch.randint(0, cfg.vocab, (ctx,), generator=g).tolist() for _ in range(MULTI - 1)]
                 torch.cuda.empty_cache()  # the 1-sequence legs leave the caching allocator fragmented for 4x tensors
-                mstep()
+                run(mp)
                 torch.cuda.synchronize()
                 dts = []  # two timed steps, the faster one is reported (the first 4x-sized step after the 1-sequence
-                for _ in range(2):  # legs still pays caching-allocator growth: 4.3 vs 5.7 s observed)
-                    for bi in (mstate["rows"] if dts else []):
-                        model.cache.free_batch(bi)
+                for _ in range(2):  # legs still pays caching-allocator growth)
                     t1 = time.perf_counter()
-                    mstate = {}
-                    mstep(mstate)
+                    run(mp)
                     torch.cuda.synchronize()
                     dts.append(time.perf_counter() - t1)
                 dt = min(dts)
+                mstate = prefill_only(llm, mp, bcp, ratio)
                 mr = roofline_decode_attn(model, mstate, "-", use_graph=not args.no_graph)
-                for bi in mstate["rows"]:
-                    model.cache.free_batch(bi)
+                llm.master_model_runner.kv_manager.free_sequences(mstate["ids"])
                 result["multi_sequence"] = {
                     "sequences_per_gpu": MULTI, "value": round(MULTI * (ctx + new) / dt, 1), "unit": "tokens/s",
                     "ms_per_step": round(dt * 1e3, 2), "steps": 2, "ms_per_step_all": [round(x * 1e3, 1) for x in dts],

@@ -1,12 +1,13 @@
-"""Thin random-weight model shell + generate loop used ONLY to measure the hot path in situ.
+"""Thin random-weight model shell used ONLY to measure the hot path in situ.
 
-The reference's engine (scheduler, model runner, models) is out of scope; measuring the
-BASELINE.json metric (prompt+generated tokens per second of one `generate` call, scheduler.py:203-205) still
-needs *something* that produces q/k/v around the attention boundary with the real shapes and issues the calls
-in the reference's order (models/llama3.py:90-112, qwen3.py:82-104).  This file is that something:
-Llama-3.1-8B / Qwen3-8B shaped bf16 weights ~N(0, 0.02^2), dense projections through torch.matmul
-(hipBLASLt), three glue kernels (tools/shell/shell_ops.hip), the compactor_vllm_amd Attention module and
-compression hooks, a PagedKVCache, greedy sampling, and a HIP-graph decode loop.
+The reference's model zoo is out of scope; measuring the BASELINE.json metric (prompt+generated
+tokens per second of one `LLM.generate` call, scheduler.py:203-205) still needs *something* that produces q/k/v around
+the attention boundary with the real shapes and issues the calls in the reference's order (models/llama3.py:90-112,
+qwen3.py:82-104).  This file is that something: Llama-3.1-8B / Qwen3-8B shaped bf16 weights ~N(0, 0.02^2), dense
+projections through torch.matmul (hipBLASLt), the glue kernels of tools/shell/shell_ops.hip, the compactor_vllm_amd
+Attention module and compression hooks.  It follows the model protocol of compactor_vllm_amd.core.model_runner
+(`model(input_ids, positions)`, `compute_logits`, `attention_modules`), so the product's engine (`LLM`) drives it:
+scheduling, the KV cache, prefill / decode orchestration and the HIP-graph decode buckets are the engine's.
 """
 from __future__ import annotations
 
@@ -27,9 +28,8 @@ from compactor_vllm_amd.compression import (  # noqa: E402
     apply_postrope_compression,
     apply_prerope_compression,
 )
-from compactor_vllm_amd.kv_cache.page_table import KVAllocationStatus, PagedKVCache  # noqa: E402
 from compactor_vllm_amd.layers.attention import Attention  # noqa: E402
-from compactor_vllm_amd.utils.context import CompressionContext, get_context, set_context  # noqa: E402
+from compactor_vllm_amd.utils.context import get_context  # noqa: E402
 
 SHELL_DIR = os.path.join(ROOT, "tools", "shell")
 SHELL_LIB = os.path.join(SHELL_DIR, "libbench_shell.so")
@@ -114,6 +114,7 @@ TINY = ShellConfig(name="tiny-shape", hidden=512, layers=2, heads=8, kv_heads=2,
 class ModelShell:
     def __init__(self, cfg: ShellConfig, device, max_model_len: int, max_seqs: int = 1, page_size: int = 128,
                  seed: int = 0):
+        del max_seqs, page_size  # the KV cache belongs to the engine now
         self.cfg, self.dev = cfg, device
         g = torch.Generator(device=device).manual_seed(seed)
         dt = torch.bfloat16
@@ -140,22 +141,42 @@ class ModelShell:
         inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, device=device, dtype=torch.float32) / D))
         ang = torch.arange(npos, device=device, dtype=torch.float32)[:, None] * inv[None, :]
         self.rope_cs = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous()
-        # paged cache: pages for the FULL uncompressed length are reserved before prefill, like the reference
-        pages_per_head = -(-max_model_len // page_size)
-        n_pages = max_seqs * cfg.kv_heads * pages_per_head + 8
-        self.cache = PagedKVCache(cfg.layers, pages_per_head, n_pages, page_size, cfg.kv_heads, D, max_seqs + 1, dt,
-                                  device)
-        self.attn = []
-        for li in range(cfg.layers):
-            a = Attention(cfg.heads, D, 1.0 / math.sqrt(D), cfg.kv_heads)
-            a.k_cache, a.v_cache, a.page_table, a.bh_seq_lens = self.cache.layer_slices(li)
-            a.page_size = page_size
-            self.attn.append(a)
-        self.store_stream = torch.cuda.Stream(device=device)
-        self.PHI = (torch.randn(D, 48, device=device, generator=g) / math.sqrt(48)).to(dt)
+        self.attn = [Attention(cfg.heads, D, 1.0 / math.sqrt(D), cfg.kv_heads) for _ in range(cfg.layers)]
+
+    # ---- the engine's model protocol (compactor_vllm_amd.core.model_runner) --------------------------------------
+    @property
+    def hf_config(self):
+        """The fields `LLMConfig` / `KVCacheManager` read from a Hugging Face config, built locally (no network)."""
+        from types import SimpleNamespace
+
+        c = self.cfg
+        return SimpleNamespace(model_type=c.name, num_hidden_layers=c.layers, num_key_value_heads=c.kv_heads,
+                               num_attention_heads=c.heads, head_dim=c.head_dim, hidden_size=c.hidden,
+                               max_position_embeddings=c.max_pos, torch_dtype=torch.bfloat16, vocab_size=c.vocab)
+
+    def attention_modules(self):
+        return self.attn
+
+    def __call__(self, input_ids: torch.Tensor, positions: torch.Tensor):
+        return self.forward(input_ids, positions)
+
+    def compute_logits(self, hidden) -> torch.Tensor:
+        """`hidden` is what `forward` returned: ("logits", t) when the fused one-token path already multiplied by the
+        LM head, else ("residual", h, delta) = the two halves of the last residual add, still un-normalised."""
+        if hidden[0] == "logits":
+            return hidden[1]
+        _, h, delta = hidden
+        ctx = get_context()
+        if ctx.is_prefill:  # only the last token of every sequence feeds the LM head (reference embed_head.py)
+            last = (ctx.cu_seqlens_q[1:] - 1).to(torch.int64)
+            h, delta = h.index_select(0, last), delta.index_select(0, last)
+        xf = torch.empty_like(h)
+        shell().shell_add_rmsnorm(h.data_ptr(), delta.data_ptr(), self.final_norm.data_ptr(), xf.data_ptr(), h.shape[0],
+                                  self.cfg.hidden, self.cfg.rms_eps, _st())
+        return linear(xf, self.lm_head)
 
     # ---- one forward pass over N packed tokens (prefill) or B single tokens (decode) -----------------------
-    def forward(self, tokens: torch.Tensor, positions: torch.Tensor, last_rows: torch.Tensor | None) -> torch.Tensor:
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor):
         cfg, S = self.cfg, shell()
         N = tokens.numel()
         H, D, I = cfg.hidden, cfg.head_dim, cfg.intermediate
@@ -200,16 +221,9 @@ class ModelShell:
             del gu
             delta = linear(act, L["wd"])
             del act
-        if last_rows is not None:
-            h = h.index_select(0, last_rows)
-            delta = delta.index_select(0, last_rows)
-        xf = torch.empty_like(h)
-        S.shell_add_rmsnorm(h.data_ptr(), delta.data_ptr(), self.final_norm.data_ptr(), xf.data_ptr(), h.shape[0], H,
-                            cfg.rms_eps, _st())
-        logits = linear(xf, self.lm_head)
-        return logits.argmax(dim=-1)  # temperature 0
+        return ("residual", h, delta)
 
-    def _forward_one_token(self, h: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+    def _forward_one_token(self, h: torch.Tensor, positions: torch.Tensor):
         """Decode step for one sequence: 8 launches per layer (norm+qkv GEMV, RoPE, attention stream, split merge,
         o GEMV, norm+gate_up GEMV, silu+down GEMV) - the RMSNorm / residual add / SiLU*mul producers are folded
         into the x-load of the GEMV that consumes them."""
@@ -249,101 +263,4 @@ class ModelShell:
         logits = torch.empty((1, cfg.vocab), dtype=dt, device=dev)
         S.shell_gemv_norm(self.lm_head.data_ptr(), ha.data_ptr(), hb.data_ptr(), delta.data_ptr(),
                           self.final_norm.data_ptr(), logits.data_ptr(), cfg.vocab, H, cfg.rms_eps, _st())
-        return logits.argmax(dim=-1)
-
-    # ---- generate: prefill (+ compression overlapped on the store stream) then HIP-graph decode ----------------
-    def generate(self, prompts: list, max_new_tokens: int, method: CompressionMethod, ratio: float,
-                 first: int = 16, last: int = 64, chunk: int = 512, use_graph: bool = True, keep_state=None,
-                 max_prefill_tokens: int = 262144):
-        dev, cfg = self.dev, self.cfg
-        B = len(prompts)
-        lens = [int(p.numel()) for p in prompts]
-        rows = []
-        for L in lens:
-            bi = self.cache.new_batch()
-            assert bi is not None
-            assert self.cache.reserve_tokens(bi, L + max_new_tokens) == KVAllocationStatus.SUCCESS
-            rows.append(bi)
-        bm = torch.tensor(rows, dtype=torch.int32, device=dev)
-        tokens = torch.cat(prompts).to(dev)
-        positions = torch.cat([torch.arange(L, device=dev, dtype=torch.int64) for L in lens])
-        cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=dev)
-        do_comp = method != CompressionMethod.NONE and ratio < 1.0
-        cc = None
-        if do_comp:
-            retain = [max(int(round(ratio * (L - first - last) * cfg.kv_heads)), 1) for L in lens]  # arguments.py:109-121
-            cc = CompressionContext(
-                compression_method=method, compression_chunk_size=chunk if method == CompressionMethod.COMPACTOR else -1,
-                batch_tokens_to_retain=torch.tensor(retain, dtype=torch.int32, device=dev),
-                max_tokens_to_retain=max(lens) * cfg.kv_heads, context_lens=lens, PHI=self.PHI,
-                protected_first_tokens=[first] * B, protected_last_tokens=[last] * B)
-        if sum(lens) <= max_prefill_tokens or B == 1:
-            set_context(is_prefill=True, do_compression=do_comp, cu_seqlens_q=cu, cu_seqlens_k=cu,
-                        max_seqlen_q=max(lens), max_seqlen_k=max(lens), batch_mapping=bm, max_bh_len=0,
-                        compression_context=cc, STORE_STREAM=self.store_stream)
-            last_rows = (cu[1:] - 1).to(torch.int64)
-            tok = self.forward(tokens, positions, last_rows)
-        else:
-            # token budget of one prefill launch exceeded (the reference scheduler's max_batched_tokens,
-            # scheduler.py:65-108): prefill the sequences one after the other, then decode them as one batch
-            toks = []
-            for b in range(B):
-                L = lens[b]
-                cub = torch.tensor([0, L], dtype=torch.int32, device=dev)
-                ccb = None
-                if do_comp:
-                    ccb = CompressionContext(
-                        compression_method=method,
-                        compression_chunk_size=chunk if method == CompressionMethod.COMPACTOR else -1,
-                        batch_tokens_to_retain=cc.batch_tokens_to_retain[b : b + 1].contiguous(),
-                        max_tokens_to_retain=L * cfg.kv_heads, context_lens=[L], PHI=self.PHI,
-                        protected_first_tokens=[first], protected_last_tokens=[last])
-                set_context(is_prefill=True, do_compression=do_comp, cu_seqlens_q=cub, cu_seqlens_k=cub, max_seqlen_q=L,
-                            max_seqlen_k=L, batch_mapping=bm[b : b + 1].contiguous(), max_bh_len=0,
-                            compression_context=ccb, STORE_STREAM=self.store_stream)
-                s0 = int(cu[b])
-                toks.append(self.forward(tokens[s0 : s0 + L], positions[s0 : s0 + L],
-                                         torch.tensor([L - 1], dtype=torch.int64, device=dev)))
-            tok = torch.cat(toks)
-        # H2 of SURVEY §3.1: lengths are written on the store stream; join before anything reads them
-        torch.cuda.current_stream().wait_stream(self.store_stream)
-        if do_comp:
-            for bi in rows:
-                self.cache.reclaim_pages(bi, future_reserve_tokens=max_new_tokens)
-        out_tokens = [tok]
-        pos = torch.tensor(lens, dtype=torch.int64, device=dev)
-        set_context(is_prefill=False, batch_mapping=bm)
-        n_dec = max_new_tokens - 1
-        if n_dec > 0:
-            if use_graph:
-                static_tok, static_pos = tok.clone(), pos.clone()
-                for _ in range(2):  # warm-up outside capture (workspace allocation, lazy inits)
-                    if n_dec <= 0:
-                        break
-                    t = self.forward(static_tok, static_pos, None)
-                    static_tok.copy_(t)
-                    static_pos.add_(1)
-                    out_tokens.append(t.clone())
-                    n_dec -= 1
-                if n_dec > 0:
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        t = self.forward(static_tok, static_pos, None)
-                        static_tok.copy_(t)
-                        static_pos.add_(1)
-                    for _ in range(n_dec):
-                        graph.replay()
-                        out_tokens.append(static_tok.clone())
-            else:
-                for _ in range(n_dec):
-                    tok = self.forward(tok, pos, None)
-                    pos = pos + 1
-                    out_tokens.append(tok)
-        torch.cuda.synchronize()
-        result = torch.stack(out_tokens, dim=1)
-        if keep_state is not None:
-            keep_state.update(rows=rows, bm=bm, lens=lens)
-        else:
-            for bi in rows:
-                self.cache.free_batch(bi)
-        return result
+        return ("logits", logits)
