@@ -306,6 +306,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=0)
     ap.add_argument("--new", type=int, default=0)
     ap.add_argument("--ratio", type=float, default=-1.0)
+    ap.add_argument("--method", default="", choices=["", "COMPACTOR", "SNAPKV", "NONE"], help="override the workload's")
     ap.add_argument("--seqs", type=int, default=1, help="sequences per GPU (the metric's configs use 1)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -348,6 +349,7 @@ def main():
     ctx = args.ctx or ctx
     new = args.new or new
     ratio = args.ratio if args.ratio >= 0 else ratio
+    method_name = args.method or method_name
     method = CompressionMethod[method_name]
     cfg = {"llama": bs.LLAMA31_8B, "qwen3": bs.QWEN3_8B, "tiny": bs.TINY}[shape]
     nseq = max(1, args.seqs) if args.workload != "C5" or args.seqs > 1 else 8

@@ -29,6 +29,7 @@ from compactor_vllm_amd.compression import (  # noqa: E402
     apply_prerope_compression,
 )
 from compactor_vllm_amd.layers.attention import Attention  # noqa: E402
+from compactor_vllm_amd.layers.rotary_embedding import fused_qkv_rope  # noqa: E402
 from compactor_vllm_amd.utils.context import get_context  # noqa: E402
 
 SHELL_DIR = os.path.join(ROOT, "tools", "shell")
@@ -54,7 +55,6 @@ def shell():
         L = ctypes.CDLL(SHELL_LIB)
         P, I, F, L64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
         L.shell_add_rmsnorm.argtypes = [P, P, P, P, I, I, F, P]
-        L.shell_rope.argtypes = [P, L64, P, P, P, P, P, I, I, I, F, P]
         L.shell_silu_mul.argtypes = [P, P, ctypes.c_long, I, P]
         L.shell_gemv.argtypes = [P, P, P, I, I, I, P]
         L.shell_gemv.restype = I
@@ -64,7 +64,7 @@ def shell():
         L.shell_gemv_norm_rope.restype = I
         L.shell_gemv_silu.argtypes = [P, P, P, I, I, P]
         L.shell_gemv_silu.restype = I
-        for f in (L.shell_add_rmsnorm, L.shell_rope, L.shell_silu_mul):
+        for f in (L.shell_add_rmsnorm, L.shell_silu_mul):
             f.restype = None
         _shell = L
     return _shell
@@ -190,25 +190,15 @@ class ModelShell:
             S.shell_add_rmsnorm(h.data_ptr(), None if delta is None else delta.data_ptr(), L["n1"].data_ptr(),
                                 x.data_ptr(), N, H, cfg.rms_eps, _st())
             qkv = linear(x, L["wqkv"])
-            q_pre = qkv[:, : self.qsz].view(N, cfg.heads, D)
-            k_pre = qkv[:, self.qsz : self.qsz + self.kvsz].view(N, cfg.kv_heads, D)
-            v = qkv[:, self.qsz + self.kvsz :].view(N, cfg.kv_heads, D)  # strided view, like the reference
-            scores = None
+            # the product's fused producer step: qkv split + (Qwen3) per-head q/k RMSNorm + RoPE in ONE
+            # launch into a fresh [N, HQ+HKV, D] buffer; k_pre = the pre-RoPE keys the Compactor scoring wants (a view of
+            # the projection for Llama, the normed keys for Qwen3, qwen3.py:88-94); v stays a strided view
             compress = ctx.is_prefill and ctx.do_compression
-            if compress and not cfg.qk_norm:
-                scores = apply_prerope_compression(q_pre, k_pre, v, ctx)
-            # RoPE (+ Qwen3 q/k-norm) of q and k in ONE launch into a fresh buffer: the pre-RoPE keys stay intact
-            # for the store-stream scoring; q / k below are strided views of it (the kernels take token strides)
-            qk = torch.empty((N, cfg.heads + cfg.kv_heads, D), dtype=h.dtype, device=h.device)
-            S.shell_rope(qkv.data_ptr(), qkv.stride(0), qk.data_ptr(), positions.data_ptr(), self.rope_cs.data_ptr(),
-                         None if L["qn"] is None else L["qn"].data_ptr(),
-                         None if L["kn"] is None else L["kn"].data_ptr(), N, cfg.heads + cfg.kv_heads, cfg.heads,
-                         cfg.rms_eps, _st())
-            q = qk[:, : cfg.heads]
-            k = qk[:, cfg.heads :]
-            if compress and cfg.qk_norm and ctx.compression_context.compression_method == CompressionMethod.COMPACTOR:
-                # Qwen3 scores the NORMED pre-RoPE keys (qwen3.py:88-94); this shell fuses the norm into RoPE
-                raise NotImplementedError("shell: Compactor pre-RoPE scoring with q/k-norm needs an un-fused norm pass")
+            q, k, v, k_pre = fused_qkv_rope(qkv, positions, self.rope_cs, cfg.heads, cfg.kv_heads, D, L["qn"], L["kn"],
+                                            cfg.rms_eps, want_prerope_k=compress)
+            scores = None
+            if compress:
+                scores = apply_prerope_compression(qkv[:, : self.qsz].view(N, cfg.heads, D), k_pre, v, ctx)
             if compress:
                 scores = apply_postrope_compression(q, k, v, scores, ctx)
             o = self.attn[li](q, k, v, scores)
@@ -246,13 +236,11 @@ class ModelShell:
             v = qkv[:, self.qsz + self.kvsz :].view(1, cfg.kv_heads, D)
             if fused_rope:  # q and k were rotated in the GEMV's epilogue, in place in the projection buffer
                 qk = qkv[:, : self.qsz + self.kvsz].view(1, cfg.heads + cfg.kv_heads, D)
+                qh, kh = qk[:, : cfg.heads], qk[:, cfg.heads :]
             else:
-                qk = torch.empty((1, cfg.heads + cfg.kv_heads, D), dtype=dt, device=dev)
-                S.shell_rope(qkv.data_ptr(), qkv.stride(0), qk.data_ptr(), positions.data_ptr(),
-                             self.rope_cs.data_ptr(), None if L["qn"] is None else L["qn"].data_ptr(),
-                             None if L["kn"] is None else L["kn"].data_ptr(), 1, cfg.heads + cfg.kv_heads, cfg.heads,
-                             cfg.rms_eps, _st())
-            o = self.attn[li](qk[:, : cfg.heads], qk[:, cfg.heads :], v, None)
+                qh, kh, _, _ = fused_qkv_rope(qkv, positions, self.rope_cs, cfg.heads, cfg.kv_heads, D, L["qn"], L["kn"],
+                                              cfg.rms_eps)
+            o = self.attn[li](qh, kh, v, None)
             delta = linear(o.view(1, self.qsz), L["wo"])
             gu = torch.empty((1, 2 * I), dtype=dt, device=dev)
             S.shell_gemv_norm(L["wgu"].data_ptr(), ha.data_ptr(), hb.data_ptr(), delta.data_ptr(), L["n2"].data_ptr(),

@@ -36,7 +36,7 @@ SIGNATURES = {
     "cvllm_zscore_segments": (_I, [_P, _I, _P, _I, _I, _P, _I, _F, _P, _I, _I, _P, _Z, _P]),
     "cvllm_chunk_attn_mass": (_I, [_P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "cvllm_leverage_workspace_bytes": (_Z, [_I, _I, _I]),
-    "cvllm_leverage_scores": (_I, [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "cvllm_leverage_scores": (_I, [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _Z, _P]),
     "cvllm_snapkv_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "cvllm_snapkv_scores": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _Z, _P]),
     "cvllm_select_workspace_bytes": (_Z, [_I, _I, _I]),
@@ -44,6 +44,8 @@ SIGNATURES = {
     "cvllm_compact_store": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                                  _I, _I, _P]),
     "cvllm_store_topk_ranked": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                                     _I, _I, _I, _I, _I, _P]),
+    "cvllm_qkv_rope_producer": (_I, [_P, _L, _P, _P, _P, _P, _F, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                      _I, _I, _I, _I, _I, _P]),
     "cvllm_rank_workspace_bytes": (_Z, [_I, _I, _I]),
     "cvllm_rank_indices": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),

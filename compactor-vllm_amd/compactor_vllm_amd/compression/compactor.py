@@ -129,12 +129,15 @@ def approximate_leverage_scores(
     scores = torch.empty((N, H), dtype=torch.float32, device=key_states.device)
     L = _lib.lib()
     kdim = phi.shape[1]
-    ws_bytes = L.cvllm_leverage_workspace_bytes(N, H, kdim)
-    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=key_states.device)
+    longest = max(chunks_lens) if chunks_lens else 0
+    ws, ws_bytes = None, 0
+    if longest > 512:  # chunks that do not fit the fused kernel's LDS image: X goes through a workspace
+        ws_bytes = L.cvllm_leverage_workspace_bytes(N, H, kdim)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=key_states.device)
     st = L.cvllm_leverage_scores(
         key_states.data_ptr(), key_states.stride(0), key_states.stride(1), phi.data_ptr(), scores.data_ptr(),
         cu.data_ptr(), len(chunks_lens), N, H, D, kdim, float(regularizer), _lib.dtype_code(key_states.dtype),
-        ws.data_ptr(), ws_bytes, _lib.stream(),
+        int(longest), _lib.ptr(ws), ws_bytes, _lib.stream(),
     )
     _lib.check(st, "cvllm_leverage_scores")
     out = scores.to(key_states.dtype)  # the reference's scores live in the model dtype (:197-210)

@@ -442,6 +442,192 @@ __global__ __launch_bounds__(256) void leverage_solve_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// a5 in ONE kernel for chunks of up to LV_FMAX rows (the engine's chunk_size = 512): sketch X = K_h PHI by MFMA straight
+// into LDS (512 x 48 fp32 = 98 KB), then column means, centred Gram, in-register Cholesky and the forward substitution
+// all read X from LDS.  HBM traffic = the chunk's keys once + its scores (the two-kernel path writes X in fp32 and
+// re-reads it three times: 2.5 x the algorithmic bytes).  Arithmetic and summation orders are those of sketch_kernel +
+// leverage_solve_kernel up to the Gram matrix, which is summed in two halves here (equal to fp32 rounding).
+constexpr int LV_FMAX = 512;
+constexpr int LV_FT = 512;  // threads: 8 waves (the single-wave Cholesky is the serial part; everything else scales)
+template <typename T, int D>
+__global__ __launch_bounds__(LV_FT) void leverage_fused_kernel(const uint16_t* __restrict__ key, int64_t s_n, int64_t s_h,
+                                                             const uint16_t* __restrict__ phi,
+                                                             float* __restrict__ scores,
+                                                             const int* __restrict__ chunk_cu, int HKV, int kdim,
+                                                             float reg) {
+  constexpr int KS = D / 16;
+  extern __shared__ __attribute__((aligned(16))) char lv_smem[];
+  float* s_X = reinterpret_cast<float*>(lv_smem);                 // [LV_FMAX][LV_LD]
+  float* s_G = s_X + LV_FMAX * LV_LD;                             // [48][LV_LD]
+  float* s_L = s_G + LV_KD * LV_LD;                               // [48][48]
+  float* s_mean = s_L + LV_KD * LV_KD;                            // [48]
+  float* s_Li = s_mean + LV_KD;                                   // [48]
+  float* s_part = s_Li + LV_KD;                                   // [256]
+  float* s_G2 = s_part + 256;                                     // [48][LV_LD] Gram of the second half of the rows
+  uint16_t(*s_phiT)[D + 8] = reinterpret_cast<uint16_t(*)[D + 8]>(lv_smem);  // aliases s_X until the fragments are loaded
+
+  const int cidx = blockIdx.x / HKV, hh = blockIdx.x % HKV;
+  const int beg = chunk_cu[cidx], end = chunk_cu[cidx + 1];
+  const int L = end - beg;
+  if (L <= 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- sketch: PHI^T fragments (as sketch_kernel), then 32-row blocks of the chunk, one per wave at a time
+  for (int e = tid; e < LV_KMAX * D; e += LV_FT) {
+    const int col = e / D, d = e % D;
+    s_phiT[col][d] = col < kdim ? phi[(size_t)d * kdim + col] : (uint16_t)0;
+  }
+  __syncthreads();
+  s16x8 pf[2][KS];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      pf[cb][s] = *reinterpret_cast<const s16x8*>(&s_phiT[cb * 32 + r][16 * s + 8 * h]);
+  __syncthreads();  // s_phiT is dead from here: its bytes become s_X
+  for (int n0 = wave * 32; n0 < L; n0 += (LV_FT / 64) * 32) {
+    const int n = n0 + r;
+    const bool valid = n < L;
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    const uint16_t* kp = key + (size_t)(beg + (valid ? n : 0)) * s_n + (size_t)hh * s_h + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4 a = valid ? *reinterpret_cast<const uint4*>(kp + 16 * s) : make_uint4(0, 0, 0, 0);
+      acc[0] = mfma32s<T>(__builtin_bit_cast(s16x8, a), pf[0][s], acc[0]);
+      acc[1] = mfma32s<T>(__builtin_bit_cast(s16x8, a), pf[1][s], acc[1]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = cb * 32 + r;
+      if (col < LV_KD) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int nn = n0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (nn < LV_FMAX) s_X[nn * LV_LD + col] = nn < L ? acc[cb][i] : 0.f;  // rows past L: zeros (as the tile loads)
+        }
+      }
+    }
+  }
+  // rows of the last partial 64-row tile that no wave touched must read as zero in the passes below
+  {
+    const int Lr = (L + 31) / 32 * 32, L64 = (L + 63) / 64 * 64;
+    for (int e = tid; e < (L64 - Lr) * LV_KD; e += LV_FT) s_X[(Lr + e / LV_KD) * LV_LD + e % LV_KD] = 0.f;
+  }
+  __syncthreads();
+  // ---- column means: thread (col, slice) sums rows slice, slice+5, ... of every 64-row tile, tile after tile
+  {
+    const int col = tid % LV_KD, sl = tid / LV_KD;  // 5 row slices for tid < 240
+    float sum = 0.f;
+    if (tid < 5 * LV_KD)
+      for (int i0 = 0; i0 < L; i0 += 64)
+        for (int rr = sl; rr < 64; rr += 5) sum += s_X[(i0 + rr) * LV_LD + col];
+    if (tid < 256) s_part[tid] = (tid < 5 * LV_KD) ? sum : 0.f;
+    __syncthreads();
+    if (tid < LV_KD) {
+      float t = 0.f;
+      for (int j = 0; j < 5; ++j) t += s_part[j * LV_KD + tid];
+      s_mean[tid] = t / (float)L;
+    }
+    __syncthreads();
+  }
+  // ---- centre in place (rows past L stay zero), then the Gram with 3 x 3 register blocks
+  {
+    const int L64 = (L + 63) / 64 * 64;
+    for (int e = tid; e < L64 * LV_KD; e += LV_FT) {
+      const int rr = e / LV_KD, cc = e % LV_KD;
+      s_X[rr * LV_LD + cc] = rr < L ? s_X[rr * LV_LD + cc] - s_mean[cc] : 0.f;
+    }
+    __syncthreads();
+    // two halves of the thread block take the two halves of the 64-row tiles; their Gram matrices are added in LDS
+    const int half = tid >> 8, ta = (tid & 255) >> 4, tb = tid & 15;
+    const int nt = L64 / 64, r_lo = half == 0 ? 0 : (nt + 1) / 2 * 64, r_hi = half == 0 ? (nt + 1) / 2 * 64 : L64;
+    float gacc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gacc[i][j] = 0.f;
+#pragma unroll 8
+    for (int rr = r_lo; rr < r_hi; ++rr) {
+      const float* row = s_X + rr * LV_LD;
+      const float a0 = row[3 * ta], a1 = row[3 * ta + 1], a2 = row[3 * ta + 2];
+      const float b0 = row[3 * tb], b1 = row[3 * tb + 1], b2 = row[3 * tb + 2];
+      gacc[0][0] = fmaf(a0, b0, gacc[0][0]); gacc[0][1] = fmaf(a0, b1, gacc[0][1]); gacc[0][2] = fmaf(a0, b2, gacc[0][2]);
+      gacc[1][0] = fmaf(a1, b0, gacc[1][0]); gacc[1][1] = fmaf(a1, b1, gacc[1][1]); gacc[1][2] = fmaf(a1, b2, gacc[1][2]);
+      gacc[2][0] = fmaf(a2, b0, gacc[2][0]); gacc[2][1] = fmaf(a2, b1, gacc[2][1]); gacc[2][2] = fmaf(a2, b2, gacc[2][2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ar = 3 * ta + i, bc = 3 * tb + j;
+        (half ? s_G2 : s_G)[ar * LV_LD + bc] = gacc[i][j] + ((ar == bc && !half) ? reg : 0.f);
+      }
+    __syncthreads();
+    for (int e = tid; e < LV_KD * LV_LD; e += LV_FT) s_G[e] += s_G2[e];
+    __syncthreads();
+  }
+  // ---- Cholesky by one wave in registers (see leverage_solve_kernel)
+  if (tid < 64) {
+    const int rown = lane < LV_KD ? lane : LV_KD - 1;
+    float a[LV_KD];
+#pragma unroll
+    for (int cc = 0; cc < LV_KD; ++cc) a[cc] = s_G[rown * LV_LD + cc];
+#pragma unroll
+    for (int j = 0; j < LV_KD; ++j) {
+      const float d = sqrtf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j)));
+      a[j] = (lane == j) ? d : a[j] / d;
+#pragma unroll
+      for (int kk = j + 1; kk < LV_KD; ++kk) {
+        const float lkj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), kk));
+        a[kk] = fmaf(-a[j], lkj, a[kk]);
+      }
+    }
+    if (lane < LV_KD) {
+#pragma unroll
+      for (int cc = 0; cc < LV_KD; ++cc) s_G[lane * LV_LD + cc] = a[cc];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < LV_KD * LV_KD; e += LV_FT) {
+    const int rr = e / LV_KD, cc = e % LV_KD;
+    s_L[e] = cc < rr ? s_G[rr * LV_LD + cc] : 0.f;
+  }
+  if (tid < LV_KD) s_Li[tid] = 1.0f / s_G[tid * LV_LD + tid];
+  __syncthreads();
+  // ---- score_i = || L^-1 xc_i ||^2, one row per thread, the centred row read from LDS
+  for (int i = tid; i < L; i += LV_FT) {
+    float y[LV_KD];
+#pragma unroll
+    for (int cc = 0; cc < LV_KD; ++cc) y[cc] = s_X[i * LV_LD + cc];
+    float sc = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < LV_KD; ++kk) {
+      float t = y[kk];
+#pragma unroll
+      for (int m4 = 0; m4 < (kk + 3) / 4; ++m4) {
+        const float4 l4 = *reinterpret_cast<const float4*>(s_L + kk * LV_KD + 4 * m4);
+        t = fmaf(-l4.x, y[4 * m4], t);
+        if (4 * m4 + 1 < kk) t = fmaf(-l4.y, y[4 * m4 + 1], t);
+        if (4 * m4 + 2 < kk) t = fmaf(-l4.z, y[4 * m4 + 2], t);
+        if (4 * m4 + 3 < kk) t = fmaf(-l4.w, y[4 * m4 + 3], t);
+      }
+      t *= s_Li[kk];
+      y[kk] = t;
+      sc = fmaf(t, t, sc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    scores[(size_t)(beg + i) * HKV + hh] = fmaxf(sc, 0.f);
+  }
+}
+constexpr size_t LV_FUSED_SMEM =
+    (size_t)(LV_FMAX * LV_LD + 2 * LV_KD * LV_LD + LV_KD * LV_KD + 2 * LV_KD + 256) * sizeof(float);
+
 // =====================================================================================================
 // a8: SnapKV.  rows = last w queries x G heads of a sequence; keys = [0, L-w).
 //   K1 (grid b, g, key tile of 128): partial (max, sum) of every window row over the tile's keys.
@@ -728,15 +914,39 @@ extern "C" size_t cvllm_leverage_workspace_bytes(int total_tokens, int HKV, int 
 
 extern "C" int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_t s_h, const void* phi, float* scores,
                                      const int32_t* chunk_cu, int n_chunks, int total_tokens, int HKV, int D,
-                                     int sketch_dim, float regularizer, int dtype, void* workspace,
+                                     int sketch_dim, float regularizer, int dtype, int max_chunk_rows, void* workspace,
                                      size_t workspace_bytes, cvllm_stream_t stream) {
   if (!key_states || !phi || !scores || !chunk_cu) return CVLLM_ERR_ARG;
   if (n_chunks <= 0 || total_tokens <= 0 || HKV <= 0) return CVLLM_ERR_ARG;
   if (sketch_dim != LV_KD) return CVLLM_ERR_SHAPE;
   if ((s_n % 8) || (s_h % 8)) return CVLLM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (max_chunk_rows > 0 && max_chunk_rows <= LV_FMAX) {
+    // every chunk fits the fused kernel's LDS image of the sketch: one launch, no workspace
+#define LF(T_, D_)                                                                                                     \
+  {                                                                                                                    \
+    static_assert((size_t)LV_KMAX * (D_ + 8) * 2 <= (size_t)LV_FMAX * LV_LD * 4, "PHI^T must fit inside the X image"); \
+    auto kern = leverage_fused_kernel<T_, D_>;                                                                         \
+    static bool attr[64] = {false};                                                                                    \
+    int dev = 0;                                                                                                       \
+    (void)hipGetDevice(&dev);                                                                                          \
+    if (dev < 0 || dev >= 64 || !attr[dev]) {                                                                          \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LV_FUSED_SMEM);    \
+      if (dev >= 0 && dev < 64) attr[dev] = true;                                                                      \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(kern, dim3(n_chunks* HKV), dim3(LV_FT), LV_FUSED_SMEM, st, (const uint16_t*)key_states, s_n, s_h, \
+                       (const uint16_t*)phi, scores, chunk_cu, HKV, sketch_dim, regularizer);                          \
+  }
+    if (dtype == CVLLM_F16 && D == 128) LF(F16, 128)
+    else if (dtype == CVLLM_F16 && D == 64) LF(F16, 64)
+    else if (dtype == CVLLM_BF16 && D == 128) LF(BF16, 128)
+    else if (dtype == CVLLM_BF16 && D == 64) LF(BF16, 64)
+    else return CVLLM_ERR_SHAPE;
+#undef LF
+    return check_launch();
+  }
   if (!workspace || workspace_bytes < cvllm_leverage_workspace_bytes(total_tokens, HKV, sketch_dim))
     return CVLLM_ERR_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
   float* X = (float*)workspace;
   long wave_tiles = (((long)total_tokens + 31) / 32) * HKV;
   int blocks = (int)((wave_tiles + 3) / 4);

@@ -142,12 +142,15 @@ int cvllm_chunk_attn_mass(const void* q, const void* k, int64_t sq_n, int64_t sk
  * int32 row offsets of the chunks (host-built exactly like split_into_chunks :62-110),
  * scores[N,HKV] f32 out: x_i^T (Xc^T Xc + reg I)^-1 x_i, X = K_h PHI centred per chunk, evaluated
  * by Cholesky in fp32 (the reference takes an SVD of the 16-bit Gram matrix; same closed form).
- * sketch_dim must be 48 (LLMConfig.leverage_sketch_size).  workspace: X in fp32.               */
+ * sketch_dim must be 48 (LLMConfig.leverage_sketch_size).  max_chunk_rows = the longest chunk (a host value:
+ * the chunk list is built on the host); when 0 < max_chunk_rows <= 512 one kernel keeps the sketch X in LDS and
+ * needs no workspace, otherwise X goes through `workspace` in fp32 (two kernels); equal up to fp32 rounding.       */
 size_t cvllm_leverage_workspace_bytes(int total_tokens, int HKV, int sketch_dim);
 int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_t s_h, const void* phi,
                           float* scores, const int32_t* chunk_cu, int n_chunks, int total_tokens,
                           int HKV, int D, int sketch_dim, float regularizer, int dtype,
-                          void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
+                          int max_chunk_rows, void* workspace, size_t workspace_bytes,
+                          cvllm_stream_t stream);
 
 /* ---- a8: SnapKV window scores -------------------------------------------------------------------
  * replaces compression/snapkv.py:332-448 query_aware_key_scores + :39-157 + :160-276.
@@ -209,6 +212,25 @@ size_t cvllm_rank_workspace_bytes(int B, int H, int max_seqlen);
 int cvllm_rank_indices(const float* scores, const int32_t* cu_seqlens_k, int64_t* out, int B,
                        int H, int max_seqlen, int k_eff, void* workspace,
                        size_t workspace_bytes, cvllm_stream_t stream);
+
+/* ---- f-2: fused producer step in front of the attention boundary -------------------------------------
+ * replaces models/llama3.py:96-110 / qwen3.py:88-102 (qkv.split + views), layers/layernorm.py:15-25 (per-head q/k
+ * RMSNorm of Qwen3), layers/rotary_embedding.py:8-17,69-80 (RoPE), and - when k_cache is given (no compression) -
+ * kv_cache/store_kv_cache.py:251-371 (prefill_store_all_kv), in ONE pass over the fused projection output.
+ * qkv[N,(HQ+2*HKV)*D] with token stride s_n (elements): q heads, then k heads, then v heads; positions[N] int64;
+ * cos_sin[max_pos,D] fp32 = cos(D/2) | sin(D/2) per position (the reference's cos_sin_cache); q_norm_w / k_norm_w [D]
+ * model dtype or both NULL; q_out[N,HQ,D] / k_out[N,HKV,D] with token strides so_q / so_k (they may be two views of one
+ * [N,HQ+HKV,D] buffer); k_pre_out[N,HKV,D] contiguous or NULL: the NORMED pre-RoPE keys (only with norm weights - without
+ * them the pre-RoPE keys are the projection itself).  k_cache != NULL: rotated K rows and V rows are also appended to
+ * the paged cache at bh_lens[b,h] + t (cu_seqlens[B+1], batch_mapping[B], bh_lens[B,HKV] updated += len_b afterwards).
+ * D in {64,128}.  Without norm weights the outputs equal the eager fp32 evaluation bit for bit.                 */
+int cvllm_qkv_rope_producer(const void* qkv, int64_t s_n, const int64_t* positions, const float* cos_sin,
+                            const void* q_norm_w, const void* k_norm_w, float eps, void* q_out,
+                            int64_t so_q, void* k_out, int64_t so_k, void* k_pre_out, void* k_cache,
+                            void* v_cache, const int32_t* cu_seqlens, const int32_t* batch_mapping,
+                            int32_t* bh_lens, const int32_t* page_table, int B, int page_size,
+                            int n_logical_pages_max, int N, int HQ, int HKV, int D, int max_pos, int dtype,
+                            cvllm_stream_t stream);
 
 #ifdef __cplusplus
 }

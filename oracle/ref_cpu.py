@@ -463,3 +463,55 @@ def ranked_store(new_keys, new_vals, indices_topk, num_tokens_to_retain, page_ta
                 v_cache[row] = new_vals[t, h]
             bh_lens[b, h] = L0 + len(kept[b][h])
     return kept
+
+
+# --------------------------------------------------------------------------------------------
+# f-2  producer step: qkv split + per-head q/k RMSNorm (Qwen3) + RoPE
+#   (cv/models/llama3.py:96-110, cv/models/qwen3.py:88-102, cv/layers/layernorm.py:15-25,
+#    cv/layers/rotary_embedding.py:8-17, 28-80)
+# --------------------------------------------------------------------------------------------
+def rope_cos_sin_cache(head_size: int, max_position: int, base: float, rope_scaling=None) -> torch.Tensor:
+    """[max_position, head_size] fp32: cos(D/2) | sin(D/2) per position, llama3 frequency scaling included (:28-68)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_size, 2, dtype=torch.float) / head_size))
+    if rope_scaling is not None:
+        rope_type, factor, low_f, high_f, old_len = rope_scaling
+        assert rope_type == "llama3"
+        low_wl, high_wl = old_len / low_f, old_len / high_f
+        wavelen = 2 * math.pi / inv_freq
+        scaled = torch.where(wavelen > low_wl, inv_freq / factor, inv_freq)
+        smooth = (old_len / wavelen - low_f) / (high_f - low_f)
+        smoothed = (1 - smooth) * scaled / factor + smooth * scaled
+        medium = ~(wavelen < high_wl) * ~(wavelen > low_wl)
+        inv_freq = torch.where(medium, smoothed, scaled)
+    t = torch.arange(max_position, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1)
+
+
+def head_rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """RMSNorm over the last dim (:15-25): fp32 x * rsqrt(mean(x^2) + eps), rounded to x.dtype, times the weight."""
+    xf = x.to(F32)
+    var = xf.pow(2).mean(dim=-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return xf.to(x.dtype) * weight
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """rotary_embedding.py:8-17: halves (x1, x2) -> (x1 cos - x2 sin, x2 cos + x1 sin) in fp32, back to x.dtype."""
+    x1, x2 = torch.chunk(x.to(F32), 2, dim=-1)
+    return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1).to(x.dtype)
+
+
+def qkv_producer(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tensor, HQ: int, HKV: int, D: int,
+                 q_norm_w: Optional[torch.Tensor] = None, k_norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6):
+    """(q_rot [N,HQ,D], k_rot [N,HKV,D], v [N,HKV,D], k_pre [N,HKV,D]) exactly as the model code produces them in front
+    of `Attention.forward`; k_pre is what `apply_prerope_compression` receives (normed for Qwen3, raw for Llama)."""
+    N = qkv.shape[0]
+    q = qkv[:, : HQ * D].reshape(N, HQ, D)
+    k = qkv[:, HQ * D : (HQ + HKV) * D].reshape(N, HKV, D)
+    v = qkv[:, (HQ + HKV) * D :].reshape(N, HKV, D)
+    if q_norm_w is not None:
+        q, k = head_rms_norm(q, q_norm_w, eps), head_rms_norm(k, k_norm_w, eps)
+    cs = cos_sin[positions.long()].unsqueeze(1)  # [N, 1, D]
+    cos, sin = cs.chunk(2, dim=-1)
+    return apply_rope(q, cos, sin), apply_rope(k, cos, sin), v, k

@@ -309,8 +309,57 @@ def gen_scoring():
         save_case(name, q=q, k=k, cu_seqlens=cu, w=32, HQ=HQ, HKV=HKV, D=D, out=ref)
 
 
+# ------------------------------------------------------------------------------------------ f-2
+def gen_producer():
+    """qkv split + (Qwen3) q/k RMSNorm + RoPE as the reference's model code runs them: the reference's own RMSNorm and
+    RotaryEmbedding modules, eager (their @torch.compile wrappers are bypassed with TORCHDYNAMO_DISABLE=1 or, failing
+    that, through __wrapped__-free re-binding below; compile only changes speed)."""
+    import torch._dynamo
+
+    torch._dynamo.config.disable = True
+    import compactor_vllm.layers.layernorm as ln
+    import compactor_vllm.layers.rotary_embedding as re
+
+    for name, dtype, N, HQ, HKV, D, base, scaling, norm in [
+        ("producer_bf16_llama", torch.bfloat16, 300, 8, 2, 128, 500000.0, ("llama3", 8.0, 1.0, 4.0, 8192), False),
+        ("producer_f16_llama_d64", torch.float16, 120, 4, 4, 64, 10000.0, None, False),
+        ("producer_bf16_qwen3", torch.bfloat16, 260, 8, 2, 128, 1000000.0, None, True),
+        ("producer_f16_qwen3", torch.float16, 90, 4, 2, 128, 1000000.0, None, True),
+    ]:
+        g = torch.Generator().manual_seed(21)
+        max_pos = 512
+        qkv = torch.randn(N, (HQ + 2 * HKV) * D, generator=g).to(dtype)
+        positions = torch.randint(0, max_pos, (N,), generator=g)
+        positions[:5] = torch.tensor([0, 1, max_pos - 1, 17, 300])
+        rope = re.RotaryEmbedding(D, D, max_pos, base, scaling)
+        q = qkv[:, : HQ * D].view(N, HQ, D)
+        k = qkv[:, HQ * D : (HQ + HKV) * D].view(N, HKV, D)
+        qw = kw = None
+        eps = 1e-6
+        if norm:
+            qn, kn = ln.RMSNorm(D, eps=eps), ln.RMSNorm(D, eps=eps)
+            with torch.no_grad():
+                qn.weight.copy_(1.0 + 0.2 * torch.randn(D, generator=g))
+                kn.weight.copy_(1.0 + 0.2 * torch.randn(D, generator=g))
+            qn, kn = qn.to(dtype), kn.to(dtype)  # the engine builds the model under default dtype = model dtype
+            qw, kw = qn.weight.detach().clone(), kn.weight.detach().clone()
+            with torch.no_grad():
+                q, k = qn(q), kn(k)
+        k_pre = k.clone()
+        with torch.no_grad():
+            q_rot, k_rot = rope(positions, q, k)
+        cs = rope.cos_sin_cache.view(max_pos, D).clone()
+        mine = O.qkv_producer(qkv, positions, O.rope_cos_sin_cache(D, max_pos, base, scaling), HQ, HKV, D, qw, kw, eps)
+        assert torch.equal(O.rope_cos_sin_cache(D, max_pos, base, scaling), cs), "cos/sin cache restatement differs"
+        assert torch.equal(mine[0], q_rot) and torch.equal(mine[1], k_rot) and torch.equal(mine[3], k_pre), name
+        print(f"{name}: oracle == reference bit for bit (q, k, pre-RoPE k, cos/sin cache)")
+        save_case(name, qkv=qkv, positions=positions, cos_sin=cs, HQ=HQ, HKV=HKV, D=D, eps=eps, base=base,
+                  max_pos=max_pos, has_norm=int(norm), has_scaling=int(scaling is not None),
+                  **({"q_norm_w": qw, "k_norm_w": kw} if norm else {}), q_rot=q_rot, k_rot=k_rot, k_pre=k_pre)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring"]
+    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring", "producer"]
     for w in which:
         {"prefill": gen_prefill, "decode": gen_decode, "stores": gen_stores, "select": gen_select,
-         "scoring": gen_scoring}[w]()
+         "scoring": gen_scoring, "producer": gen_producer}[w]()

@@ -275,7 +275,7 @@ def test_scoring_random(dev, seed):
         nb = L.cvllm_leverage_workspace_bytes(N, HKV, 48)
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
         st = L.cvllm_leverage_scores(kd.data_ptr(), kd.stride(0), kd.stride(1), pd.data_ptr(), scores.data_ptr(),
-                                     cuc.data_ptr(), len(chunks), N, HKV, D, 48, 5e-3, 1, ws.data_ptr(), nb,
+                                     cuc.data_ptr(), len(chunks), N, HKV, D, 48, 5e-3, 1, max(chunks), ws.data_ptr(), nb,
                                      torch.cuda.current_stream().cuda_stream)
         assert st == 0
         refl = O.leverage_scores(k, lens, PHI, normalize=False, chunk_size=512, out_dtype=torch.float32)

@@ -170,3 +170,18 @@ def test_snapkv_oracle(name):
             assert torch.equal(fin, torch.isfinite(a))
             assert torch.allclose(a[fin], r[fin], rtol=1e-4, atol=1e-5)
         s += L
+
+
+# ------------------------------------------------------------------------------------------ f-2
+@pytest.mark.parametrize("name", list_cases("producer_"))
+def test_producer_oracle(name):
+    """qkv split + q/k RMSNorm + RoPE restatement vs the reference modules' outputs: bit for bit (plain torch ops on
+    both sides), cos/sin cache included."""
+    c = load_case(name)
+    HQ, HKV, D = c["HQ"], c["HKV"], c["D"]
+    scaling = ("llama3", 8.0, 1.0, 4.0, 8192) if c["has_scaling"] else None
+    cs = O.rope_cos_sin_cache(D, c["max_pos"], c["base"], scaling)
+    assert torch.equal(cs, c["cos_sin"])
+    q, k, v, k_pre = O.qkv_producer(c["qkv"], c["positions"], cs, HQ, HKV, D, c.get("q_norm_w"), c.get("k_norm_w"), c["eps"])
+    assert torch.equal(q, c["q_rot"]) and torch.equal(k, c["k_rot"]) and torch.equal(k_pre, c["k_pre"])
+    assert torch.equal(v.reshape(v.shape[0], -1), c["qkv"][:, (HQ + HKV) * D :])

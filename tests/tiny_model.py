@@ -14,6 +14,7 @@ import torch
 
 from compactor_vllm_amd.compression import apply_postrope_compression, apply_prerope_compression
 from compactor_vllm_amd.layers.attention import Attention
+from compactor_vllm_amd.layers.rotary_embedding import fused_qkv_rope
 from compactor_vllm_amd.utils.context import get_context
 
 BLOCK = 16
@@ -70,6 +71,7 @@ class TinyModel:
         inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, device=device, dtype=torch.float32) / D))
         ang = torch.arange(cfg.max_position_embeddings, device=device, dtype=torch.float32)[:, None] * inv[None, :]
         self.cos, self.sin = ang.cos(), ang.sin()
+        self.cos_sin = torch.cat([self.cos, self.sin], dim=-1).contiguous()  # the reference's cos_sin_cache layout
         self.attn = [Attention(cfg.num_attention_heads, D, 1.0 / math.sqrt(D), cfg.num_key_value_heads)
                      for _ in range(cfg.num_hidden_layers)]
 
@@ -89,14 +91,13 @@ class TinyModel:
         for li, L in enumerate(self.layers):
             x = rmsnorm(h, L["n1"], cfg.rms_norm_eps)
             qkv = linear(x, L["wqkv"])
-            q = qkv[:, : self.qsz].view(N, cfg.num_attention_heads, D)
-            k = qkv[:, self.qsz : self.qsz + self.kvsz].view(N, cfg.num_key_value_heads, D)
-            v = qkv[:, self.qsz + self.kvsz :].view(N, cfg.num_key_value_heads, D)
+            # the product's fused producer step: split + RoPE in one launch (k_pre = the pre-RoPE keys for the scoring)
+            q, k, v, k_pre = fused_qkv_rope(qkv, positions, self.cos_sin, cfg.num_attention_heads,
+                                            cfg.num_key_value_heads, D, want_prerope_k=True)
             scores = None
             compress = ctx.is_prefill and ctx.do_compression
             if compress:
-                scores = apply_prerope_compression(q, k, v, ctx)
-            q, k = self._rope(q, positions), self._rope(k, positions)
+                scores = apply_prerope_compression(qkv[:, : self.qsz].view(N, cfg.num_attention_heads, D), k_pre, v, ctx)
             if compress:
                 scores = apply_postrope_compression(q, k, v, scores, ctx)
             o = self.attn[li](q, k, v, scores)
