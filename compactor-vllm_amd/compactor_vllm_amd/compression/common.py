@@ -132,6 +132,29 @@ def extract_and_store_top_kv(
     return kept, new_lens
 
 
+def compact_cache_inplace(
+    kept_idx: torch.Tensor,  # [B, H, max_len] int32 ascending token indices (select_retained)
+    new_lens: torch.Tensor,  # [B, H] int32 = dst_base + kept count
+    dst_base: torch.Tensor,  # [B, H] int32 first destination row
+    src_base: torch.Tensor,  # [B, H] int32 logical row of token 0 (>= dst_base)
+    page_table: torch.Tensor,
+    batch_mapping: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    PAGE_SIZE: int,
+) -> None:
+    """Move the kept rows of every (b, h) down inside the paged cache (last chunk of a chunked prefill): the same final
+    cache as `extract_and_store_top_kv` fed with the whole sequence's packed keys / values."""
+    _lib.require_cuda(kept_idx, new_lens, dst_base, src_base, page_table, batch_mapping, k_cache, v_cache)
+    B, H, max_len = kept_idx.shape
+    st = _lib.lib().cvllm_compact_cache_inplace(
+        kept_idx.data_ptr(), new_lens.data_ptr(), _lib.i32(dst_base).data_ptr(), _lib.i32(src_base).data_ptr(),
+        page_table.data_ptr(), _lib.i32(batch_mapping).data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), B, H,
+        k_cache.shape[-1], int(max_len), int(PAGE_SIZE), page_table.shape[-1], _lib.dtype_code(k_cache.dtype),
+        _lib.stream())
+    _lib.check(st, "cvllm_compact_cache_inplace")
+
+
 def scores_to_retain_indices(
     scores: torch.Tensor,
     cu_seqlens_k: torch.Tensor,

@@ -36,6 +36,9 @@ class CompactorCompression(BaseCompressionMethod):
     @staticmethod
     def post_rope_scoring(q, k, v, pre_rope_scores: torch.Tensor, context) -> Optional[torch.Tensor]:
         cc = context.compression_context
+        if getattr(context, "chunk", None) is not None:
+            return maybe_execute_in_stream(_chunked_post_rope, q, k, v, pre_rope_scores, context,
+                                           STORE_STREAM=context.STORE_STREAM)
         # The reference runs this on the main stream while `pre_rope_scores` is still being produced on
         # STORE_STREAM with no dependency edge (hazard H1).  Here it runs on STORE_STREAM like every
         # other piece of the scoring -> select -> compaction chain: in order behind the pre-RoPE scores (no hazard,
@@ -57,6 +60,28 @@ class CompactorCompression(BaseCompressionMethod):
             accum_blending=0.5,
             STORE_STREAM=context.STORE_STREAM,
         )
+
+
+def _chunked_post_rope(q, k, v, pre_chunk, context):
+    """Chunked prefill (utils/chunked.py): stash this chunk's leverage scores and raw attention mass; on the last chunk
+    finish exactly like the one-shot call - z-score of the mass over the WHOLE sequence + 0.5 * leverage, protected
+    tokens <- +inf - and return the [total_len, HKV] scores (None before the last chunk: nothing is evicted yet)."""
+    ch, cc = context.chunk, context.compression_context
+    st = ch.state
+    li = st.next_layer()
+    mass = non_causal_attn_scores(q, k, v, context.cu_seqlens_q, context.max_seqlen_q,
+                                  chunk_size=CompactorCompression.chunk_size, sm_scale=1.0, normalize=False)
+    pre_all, mass_all = st.buffers(li, pre_chunk, q.device)
+    mass_all[ch.start : ch.start + ch.length] = mass
+    pre_all[ch.start : ch.start + ch.length] = pre_chunk
+    if not ch.is_last:
+        return None
+    cu = _cu_from_lens([ch.total_len], q.device)
+    rng = _protected_ranges([ch.total_len], cc.protected_first_tokens, cc.protected_last_tokens, ch.total_len)
+    prot = torch.tensor(rng, dtype=torch.int32).to(q.device, non_blocking=True) if rng else None
+    out = mass_all  # the state is not needed after the last chunk: normalise in place
+    zscore_segments_(out, cu, pre_all, 0.5, prot)
+    return out
 
 
 def split_into_chunks(xs, chunk_size):

@@ -23,6 +23,8 @@ class SnapKVCompression(BaseCompressionMethod):
 
     @staticmethod
     def post_rope_scoring(q, k, v, pre_rope_scores, context) -> Optional[torch.Tensor]:
+        if getattr(context, "chunk", None) is not None:
+            return maybe_execute_in_stream(_chunked_post_rope, q, k, context, STORE_STREAM=context.STORE_STREAM)
         return maybe_execute_in_stream(
             query_aware_key_scores,
             q,
@@ -33,6 +35,26 @@ class SnapKVCompression(BaseCompressionMethod):
             max_seqlen_k=context.max_seqlen_k,
             STORE_STREAM=context.STORE_STREAM,
         )
+
+
+def _chunked_post_rope(q, k, context):
+    """Chunked prefill (utils/chunked.py): SnapKV scores once, on the last chunk - the window's queries are in this
+    chunk, the keys are [rows of the earlier chunks read back from this layer's cache || this chunk's keys]."""
+    ch = context.chunk
+    li = ch.state.next_layer()
+    if not ch.is_last:
+        return None
+    attn = ch.state.attn[li]
+    HKV, D = k.shape[1], k.shape[2]
+    k_all = torch.empty((ch.total_len, HKV, D), dtype=k.dtype, device=k.device)
+    if ch.start > 0:
+        pos = torch.arange(ch.start, device=k.device)
+        pages = attn.page_table[context.batch_mapping[0].long()].long()  # [HKV, P] of the sequence's row
+        rows = pages[:, pos // attn.page_size] * attn.page_size + (pos % attn.page_size)[None, :]  # [HKV, start]
+        k_all[: ch.start] = attn.k_cache[rows].transpose(0, 1)
+    k_all[ch.start :] = k
+    cu_k = torch.tensor([0, ch.total_len], dtype=torch.int32).to(k.device, non_blocking=True)
+    return query_aware_key_scores(q, k_all, context.cu_seqlens_q, cu_k, w=32, max_seqlen_k=ch.total_len)
 
 
 def query_aware_key_scores(

@@ -45,6 +45,7 @@ class KVCacheManager:
         self.paged_cache: Optional[PagedKVCache] = None
         self.max_batched_tokens = max_batched_tokens
         self.seq_id_to_batch: dict = {}
+        self.chunked_prefill = True  # prompts longer than max_batched_tokens are prefilled in chunks (scheduler.py)
 
     # ---- sizing ------------------------------------------------------------------------------------------------
     def bytes_per_page_all_layers(self) -> int:

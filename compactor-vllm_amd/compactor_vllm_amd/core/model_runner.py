@@ -33,9 +33,10 @@ from ..config.engine_config import LLMConfig
 from ..layers.sampler import Sampler
 from ..utils.arguments import (DecodeBatchArguments, DecodeBatchOutput, PrefillBatchArguments, build_prefill_args,
                                make_phi)
+from ..utils.chunked import ChunkedPrefillState, PrefillChunk, chunk_boundaries
 from ..utils.context import CompressionContext, reset_context, set_context
 from ..utils.sequence import Sequence
-from .memory_manager import KVCacheManager
+from .memory_manager import KVCacheManager, attention_modules
 from .scheduler import Scheduler
 
 logger = logging.getLogger(__name__)
@@ -91,6 +92,42 @@ class ModelRunner:
         finally:
             reset_context()
 
+    @torch.inference_mode()
+    def run_prefill_chunked(self, a: PrefillBatchArguments, batch_mapping: torch.Tensor) -> torch.Tensor:
+        """One sequence whose prompt exceeds `max_batched_tokens`: chunks of a multiple of 512 tokens, each
+        attending to [its own cached prefix || itself] and written to the cache uncompressed; scoring state carried in
+        a `ChunkedPrefillState`; compression applied in place after the last chunk (layers/attention.py).  Returns the
+        logits of the prompt's last token."""
+        assert a.B == 1
+        total = int(a.context_lens[0])
+        cuts = chunk_boundaries(total, self.max_batched_tokens)
+        state = ChunkedPrefillState(total, self.num_kv_heads, attention_modules(self.model))
+        logits = None
+        for ci in range(len(cuts) - 1):
+            s0, s1 = cuts[ci], cuts[ci + 1]
+            n = s1 - s0
+            cu = torch.tensor([0, n], dtype=torch.int32, device=self.device)
+            cc = CompressionContext(
+                compression_method=a.compression_method, compression_chunk_size=a.compression_chunk_size,
+                batch_tokens_to_retain=a.batch_tokens_to_retain, max_tokens_to_retain=a.max_tokens_to_retain,
+                context_lens=[n], PHI=a.PHI, protected_first_tokens=a.protected_first,
+                protected_last_tokens=a.protected_last)
+            last = ci == len(cuts) - 2
+            state.begin_chunk()
+            set_context(is_prefill=True, do_compression=a.do_compression, cu_seqlens_q=cu, cu_seqlens_k=cu,
+                        max_seqlen_q=n, max_seqlen_k=n, batch_mapping=batch_mapping, max_bh_len=s0,
+                        compression_context=cc, STORE_STREAM=self.store_stream,
+                        attention_backend=self.config.attention_backend,
+                        chunk=PrefillChunk(start=s0, length=n, is_last=last, state=state))
+            try:
+                hidden = self.model(a.input_ids[s0:s1], a.positions[s0:s1])
+                if last:
+                    logits = self.model.compute_logits(hidden)
+            finally:
+                reset_context()
+            self._join_store_stream()  # the next chunk's attention reads this chunk's rows and lengths
+        return logits
+
     def _join_store_stream(self) -> None:
         if self.store_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.store_stream)
@@ -116,7 +153,10 @@ class ModelRunner:
                         raise RuntimeError("failed to allocate pages for sequences")
                     temps = torch.tensor([s.sampling_params.temperature for s in seqs], dtype=torch.float32,
                                          device=self.device)
-                    logits = self.run_prefill(args, rows)
+                    if len(seqs) == 1 and seqs[0].prompt_len > self.max_batched_tokens:
+                        logits = self.run_prefill_chunked(args, rows)
+                    else:
+                        logits = self.run_prefill(args, rows)
                     tokens = self.sampler(logits, temps)
                     pending_out.append((tokens, ids))
                     # H2: the per-head lengths are written on the store stream

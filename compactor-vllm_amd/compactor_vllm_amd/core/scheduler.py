@@ -44,9 +44,13 @@ class Scheduler:
         page_size, heads = self.manager.page_size, self.manager.num_kv_heads
         chosen: List[Sequence] = []
         used = 0
+        chunked_ok = bool(getattr(self.manager, "chunked_prefill", False))
         for seq_id in self.pending_sequence_ids:
             seq = self.allseq_mapping[seq_id]
             need = cdiv(seq.prompt_len + seq.sampling_params.max_new_tokens, page_size) * heads
+            if chunked_ok and not chosen and seq.prompt_len > budget and rows > 0 and need < pages:
+                # extension: a prompt longer than one prefill launch goes alone and is prefilled in chunks
+                return [seq]
             if seq.prompt_len + used <= budget and rows > 0 and need < pages:
                 chosen.append(seq)
                 used += seq.prompt_len

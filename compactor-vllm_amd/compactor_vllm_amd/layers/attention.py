@@ -19,7 +19,7 @@ from torch import nn
 
 from ..attention.sparse_decode_kernel import fused_decode_step, head_sparse_decode_attention
 from ..attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
-from ..compression.common import extract_and_store_top_kv
+from ..compression.common import compact_cache_inplace, extract_and_store_top_kv, select_retained
 from ..config.engine_config import AttentionBackend
 from ..kv_cache.store_kv_cache import decode_store_kv, prefill_store_all_kv
 from ..utils.context import Context, get_context
@@ -69,7 +69,8 @@ class Attention(nn.Module):
         lengths_before = seq_lens.clone()
         common = dict(self._cache_args(), batch_mapping=batch_mapping, bh_lens=seq_lens,
                       STORE_STREAM=context.STORE_STREAM)
-        compress = context.do_compression and scores is not None
+        chunk = getattr(context, "chunk", None)
+        compress = context.do_compression and scores is not None and chunk is None
         if compress:
             cc = context.compression_context
             assert cc is not None
@@ -81,11 +82,30 @@ class Attention(nn.Module):
             maybe_execute_in_stream(
                 prefill_store_all_kv, new_keys=k, new_values=v, cu_seqlens_k=context.cu_seqlens_k,
                 max_seqlen_k=context.max_seqlen_k, **common)
-        return causal_sparse_varlen_with_cache(
+        out = causal_sparse_varlen_with_cache(
             q, k, v, self.k_cache, self.v_cache, seq_lens_bh=lengths_before, global_page_table=self.page_table,
             batch_mapping=batch_mapping, cu_seqlens_q=context.cu_seqlens_q, max_seqlen_q=context.max_seqlen_q,
             max_seqlen_k_cache=context.max_bh_len, HKV=int(self.num_kv_heads), PAGE_SIZE=self.page_size,
             sm_scale=self.scale)
+        if chunk is not None and chunk.is_last and context.do_compression and scores is not None:
+            # last chunk of a chunked prefill: the whole prompt now sits in the cache uncompressed; select over the
+            # whole sequence's scores and compact the cache in place.  Enqueued on the store stream BEHIND the attention
+            # above (maybe_execute_in_stream makes that stream wait for the caller's stream first): the attention reads
+            # the very rows the compaction rewrites.
+            maybe_execute_in_stream(self._compact_whole_sequence, context, chunk, scores, seq_lens,
+                                    STORE_STREAM=context.STORE_STREAM)
+        return out
+
+    def _compact_whole_sequence(self, context: Context, chunk, scores, seq_lens) -> None:
+        cc = context.compression_context
+        dev = scores.device
+        cu = torch.tensor([0, chunk.total_len], dtype=torch.int32).to(dev, non_blocking=True)
+        base = torch.zeros_like(seq_lens)  # the sequence's cache was empty before its first chunk
+        kept, new_lens = select_retained(scores, cu, chunk.total_len, cc.batch_tokens_to_retain, context.batch_mapping,
+                                         base, self.page_size, True)
+        compact_cache_inplace(kept, new_lens, base, base, self.page_table, context.batch_mapping, self.k_cache,
+                              self.v_cache, self.page_size)
+        seq_lens.copy_(new_lens)  # written back to the layer's table by forward() on the same stream
 
     def _decode_reference_order(self, context: Context, q, k, v, seq_lens):
         """append the token's K/V row, then attend over the whole cache (reference `:127-150`)"""

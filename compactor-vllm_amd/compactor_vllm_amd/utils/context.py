@@ -44,6 +44,8 @@ _CONTEXT_FIELDS = (
     # extension (not in the reference): an upper bound of the longest cached sequence of a decode batch, 0 = unknown.
     # Only tunes the decode kernel's split count (short contexts take fewer splits); never affects results.
     ("decode_len_hint", int, 0),
+    # extension: utils.chunked.PrefillChunk while a long prompt is prefilled in chunks, else None
+    ("chunk", Any, None),
 )
 
 

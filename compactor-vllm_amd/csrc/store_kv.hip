@@ -111,6 +111,68 @@ __global__ __launch_bounds__(256) void compact_store_kernel(
   }
 }
 
+// ---- f-3: compaction IN PLACE, for the last chunk of a chunked prefill -----------------------------------------------
+// The chunks of a long prompt were written to the cache uncompressed (rows src_base + t for token t); selection then
+// runs once over the whole sequence and the kept rows of every (b,h) move down to slots dst_base.. in token order.
+// With an ascending kept list, slot j receives the row of token t_j >= j, so (dst_base <= src_base) a row never moves
+// up.  One workgroup owns a (b,h) and walks its list in tiles of TILE rows: all rows of a tile are loaded into registers,
+// the workgroup synchronises, then they are stored.  Tile i writes slots below dst_base + TILE*(i+1), and every source
+// of a later tile lies at or above src_base + TILE*(i+1) - so later tiles can never read a slot an earlier tile wrote;
+// inside a tile the barrier separates all reads from all writes.  The next tile's loads are issued before the current
+// tile's stores (they cannot collide for the same reason), which keeps two tiles of traffic in flight.
+template <int D>
+__global__ __launch_bounds__(256) void compact_inplace_kernel(
+    const int* __restrict__ kept_idx, const int* __restrict__ new_lens, const int* __restrict__ dst_base,
+    const int* __restrict__ src_base, const int* __restrict__ page_table, const int* __restrict__ bmap,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int H, int max_seqlen, int PS, int NLP) {
+  constexpr int LPR = D / 8;          // lanes per row
+  constexpr int RPP = 256 / LPR;      // rows per pass of the workgroup
+  constexpr int PASSES = 8;           // rows per thread and tile
+  constexpr int TILE = RPP * PASSES;  // 128 rows at D = 128
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh % H;
+  const int d0 = dst_base[bh], s0 = src_base[bh];
+  const int cnt = new_lens[bh] - d0;
+  const int dl = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int* list = kept_idx + (size_t)bh * max_seqlen;
+  const int* pt = page_table + ((size_t)bmap[b] * H + h) * NLP;
+  auto row_addr = [&](int pos) { return ((size_t)pt[pos / PS] * PS + pos % PS) * D + dl * 8; };
+  uint4 kb[2][PASSES], vb[2][PASSES];
+  auto load_tile = [&](int t0, uint4(&kk)[PASSES], uint4(&vv)[PASSES]) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int j = t0 + p * RPP + rl;
+      if (j < cnt) {
+        const size_t a = row_addr(s0 + list[j]);
+        kk[p] = *reinterpret_cast<const uint4*>(kc + a);
+        vv[p] = *reinterpret_cast<const uint4*>(vc + a);
+      }
+    }
+  };
+  auto store_tile = [&](int t0, const uint4(&kk)[PASSES], const uint4(&vv)[PASSES]) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int j = t0 + p * RPP + rl;
+      if (j < cnt) {
+        const size_t a = row_addr(d0 + j);
+        *reinterpret_cast<uint4*>(kc + a) = kk[p];
+        *reinterpret_cast<uint4*>(vc + a) = vv[p];
+      }
+    }
+  };
+  if (cnt <= 0) return;
+  load_tile(0, kb[0], vb[0]);
+  for (int t0 = 0; t0 < cnt; t0 += 2 * TILE) {
+    if (t0 + TILE < cnt) load_tile(t0 + TILE, kb[1], vb[1]);
+    __syncthreads();  // every row of tile t0 is in registers (the barrier also drains each wave's loads)
+    store_tile(t0, kb[0], vb[0]);
+    if (t0 + TILE >= cnt) break;
+    if (t0 + 2 * TILE < cnt) load_tile(t0 + 2 * TILE, kb[0], vb[0]);
+    __syncthreads();
+    store_tile(t0 + TILE, kb[1], vb[1]);
+  }
+}
+
 // ---- ranked-list variant (reference argument list): store_kv_cache.py:81-248 --------------------------
 // One workgroup per sequence walks the rank list in order; the slot of rank r inside its head is the
 // number of earlier ranks of the same head (deterministic replacement of the reference's atomics).
@@ -303,6 +365,24 @@ extern "C" int cvllm_compact_store(const void* new_keys, const void* new_vals, i
                        (const uint16_t*)new_keys, (const uint16_t*)new_vals, sk_n, sk_h, sv_n, sv_h, kept_idx,
                        new_lens, cu_seqlens_k, bh_lens0, page_table, batch_mapping, (uint16_t*)k_cache,
                        (uint16_t*)v_cache, H, max_seqlen, page_size, n_logical_pages_max, tiles);
+  });
+  return check_launch();
+}
+
+extern "C" int cvllm_compact_cache_inplace(const int32_t* kept_idx, const int32_t* new_lens, const int32_t* dst_base,
+                                          const int32_t* src_base, const int32_t* page_table,
+                                          const int32_t* batch_mapping, void* k_cache, void* v_cache, int B, int H,
+                                          int D, int max_seqlen, int page_size, int n_logical_pages_max, int dtype,
+                                          cvllm_stream_t stream) {
+  if (!kept_idx || !new_lens || !dst_base || !src_base || !page_table || !batch_mapping || !k_cache || !v_cache)
+    return CVLLM_ERR_ARG;
+  if (B <= 0 || H <= 0 || max_seqlen <= 0 || page_size <= 0 || n_logical_pages_max <= 0) return CVLLM_ERR_ARG;
+  if (dtype != CVLLM_F16 && dtype != CVLLM_BF16) return CVLLM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_D(D, {
+    hipLaunchKernelGGL((compact_inplace_kernel<DD>), dim3(B * H), dim3(256), 0, st, kept_idx, new_lens, dst_base,
+                       src_base, page_table, batch_mapping, (uint16_t*)k_cache, (uint16_t*)v_cache, H, max_seqlen,
+                       page_size, n_logical_pages_max);
   });
   return check_launch();
 }

@@ -213,6 +213,19 @@ int cvllm_rank_indices(const float* scores, const int32_t* cu_seqlens_k, int64_t
                        int H, int max_seqlen, int k_eff, void* workspace,
                        size_t workspace_bytes, cvllm_stream_t stream);
 
+/* ---- f-3: compaction in place (last chunk of a chunked prefill) -------------------------------------------
+ * The chunks of a long prompt went into the cache uncompressed (attention/sparse_varlen_kernel.py:362-401 attends to
+ * [cached prefix || chunk]); after the last chunk the selection of cvllm_select_topk runs over the whole sequence and
+ * the kept rows of every (b,h) are moved, inside the cache, from logical rows src_base[b,h] + kept_idx[b,h,j] to
+ * dst_base[b,h] + j (token order; dst_base <= src_base).  Same final cache bytes and lengths as cvllm_compact_store
+ * fed with the packed keys / values of the whole sequence.  kept_idx [B,H,max_seqlen], new_lens [B,H] (= dst_base +
+ * count) are the outputs of cvllm_select_topk called with bh_lens0 = dst_base.                               */
+int cvllm_compact_cache_inplace(const int32_t* kept_idx, const int32_t* new_lens, const int32_t* dst_base,
+                                const int32_t* src_base, const int32_t* page_table,
+                                const int32_t* batch_mapping, void* k_cache, void* v_cache, int B, int H,
+                                int D, int max_seqlen, int page_size, int n_logical_pages_max, int dtype,
+                                cvllm_stream_t stream);
+
 /* ---- f-2: fused producer step in front of the attention boundary -------------------------------------
  * replaces models/llama3.py:96-110 / qwen3.py:88-102 (qkv.split + views), layers/layernorm.py:15-25 (per-head q/k
  * RMSNorm of Qwen3), layers/rotary_embedding.py:8-17,69-80 (RoPE), and - when k_cache is given (no compression) -
