@@ -24,6 +24,8 @@ SIGNATURES = {
     "cvllm_error_string": (c_char_p, [_I]),
     "cvllm_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "cvllm_decode_attn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cvllm_decode_attn_lse": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cvllm_decode_merge_shards": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cvllm_decode_append_attn": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I,
                                       _I, _F, _I, _I, _I, _P]),
     "cvllm_decode_merge_status": (_I, [_P, _P]),

@@ -89,8 +89,11 @@ def head_sparse_decode_attention(
     PAGE_SIZE: int,
     sm_scale: float = None,
     key_split: int = None,
+    *,
+    return_lse: bool = False,
 ):
-    """Same contract as the reference wrapper (sparse_decode_kernel.py:10-68).
+    """Same contract as the reference wrapper (sparse_decode_kernel.py:10-68).  `return_lse=True` (extension, used by
+    attention/cross_gpu_decode.py) also returns lse [B, HQ] fp32: the natural-log LSE of the scaled logits.
 
     q: [B, HQ, D] (or [B, HQ, 1, D]); k, v: global caches [CACHE_SIZE, D]; seq_lens_bh [B, HKV]
     int32 (lengths including the current token); global_page_table [MAX_BATCHES, HKV, P];
@@ -132,6 +135,15 @@ def head_sparse_decode_attention(
     if n_splits > 1:
         ws_bytes = L.cvllm_decode_workspace_bytes(B, HQ, D, n_splits)
         ws = _workspace(q.device, ws_bytes)
+    if return_lse:
+        lse = torch.empty((B, HQ), dtype=torch.float32, device=q.device)
+        st = L.cvllm_decode_attn_lse(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), seq_lens_bh.data_ptr(),
+            page_table.data_ptr(), batch_mapping.data_ptr(), _lib.ptr(ws), ws_bytes, B, HQ, HKV, D, PAGE_SIZE,
+            n_lp, float(sm_scale), n_splits, _lib.dtype_code(q.dtype), _lib.stream(),
+        )
+        _lib.check(st, "cvllm_decode_attn_lse")
+        return out, lse
     st = L.cvllm_decode_attn(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), seq_lens_bh.data_ptr(),
         page_table.data_ptr(), batch_mapping.data_ptr(), _lib.ptr(ws), ws_bytes, B, HQ, HKV, D, PAGE_SIZE,

@@ -337,12 +337,12 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int HKV, int PS, int NLP, int S, float scale,
     int lens_by_row, int reserved, int64_t sk_b, int64_t sk_h, int64_t sv_b, int64_t sv_h,
     uint16_t* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_lse,
-    unsigned* __restrict__ merge_ws, unsigned* __restrict__ err_word, int mode) {
+    unsigned* __restrict__ merge_ws, unsigned* __restrict__ err_word, int mode, float* __restrict__ lse_out) {
   // hipcc fetches kernel arguments lazily, one dependent s_load + wait in front of each first use (four round trips
   // in this kernel's prologue); naming them all here puts every fetch into one clause.
   asm volatile("" ::"s"(vc), "s"(HKV), "s"(PS), "s"(NLP), "s"(S), "s"(scale), "s"(lens_by_row), "s"(reserved));
   asm volatile("" ::"s"(sk_b), "s"(sk_h), "s"(sv_b), "s"(sv_h), "s"(out), "s"(part_o), "s"(part_lse), "s"(merge_ws),
-               "s"(err_word), "s"(mode));
+               "s"(err_word), "s"(mode), "s"(lse_out));
   DEC_TS(0);
   DEC_RT(0);
   constexpr int LPR = D / 8;
@@ -667,6 +667,8 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       const float inv = pden > 0.f ? 1.f / pden : 0.f;  // empty (L == 0, RESERVED rows): zeros
 #pragma unroll
       for (int o = 0; o < OPT; ++o) out[((size_t)b * HQ + h * G + g_t) * D + d0 + o] = to16<T>(pnum[o] * inv);
+      // natural-log LSE of the scaled logits this call saw (-inf for an empty row): what a cross-device merge needs
+      if (lse_out != nullptr && d0 == 0) lse_out[(size_t)b * HQ + h * G + g_t] = pden > 0.f ? pM + __logf(pden) : -INFINITY;
     }
     if (append && tid == 0) seq_lens[lidx] = L_old + 1;
   } else if (mode != 2) {
@@ -808,6 +810,7 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       // the denominator by wave reductions that every wave does for itself (no barrier), numerators by all threads.
       float* sP = sV + (NE + 2 * DEC_MAX_SPLITS);  // [nel][SXW] partial sums of the weighted numerators
       float* sDs = sMx;                            // [nh] sum_s w_s * den_s
+      float* sMxv = sP + (NE + 2 * DEC_MAX_SPLITS);   // [nh] max_s M_s (for the optional LSE output)
       float part[2] = {0.f, 0.f};                  // nel <= 2 * ELW whenever ELW < 256; else one el per pass (below)
       for (int gi = 0; gi < nh; ++gi) {
         float mv = -INFINITY;
@@ -819,7 +822,10 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
           dv += (mm == -INFINITY) ? 0.f : __expf(mm - mx) * sDen[gi * S + sx];
         }
         dv = wave_allreduce_sum_fixed(dv);  // fixed tree: bit-reproducible
-        if (tid == 0) sDs[gi] = dv;
+        if (tid == 0) {
+          sDs[gi] = dv;
+          sMxv[gi] = mx;
+        }
         int pi = 0;
         for (int el0 = 0; el0 < nel; el0 += ELW, ++pi) {
           const int el = el0 + el_l;
@@ -854,6 +860,8 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
             float o = ds > 0.f ? a / ds : 0.f;  // every split empty (L == 0, RESERVED rows): zeros
             if (failed) o = __uint_as_float(0x7fc00000u);
             out[((size_t)b * HQ + h * G) * D + e0 + el] = to16<T>(o);
+            if (lse_out != nullptr && (e0 + el) % D == 0)
+              lse_out[(size_t)b * HQ + h * G + (e0 + el) / D] = ds > 0.f ? sMxv[(e0 + el) / D - glo] + __logf(ds) : -INFINITY;
           }
         }
       } else {
@@ -864,6 +872,8 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
           float o = ds > 0.f ? a / ds : 0.f;
           if (failed) o = __uint_as_float(0x7fc00000u);
           out[((size_t)b * HQ + h * G) * D + e0 + el] = to16<T>(o);
+          if (lse_out != nullptr && (e0 + el) % D == 0)
+            lse_out[(size_t)b * HQ + h * G + (e0 + el) / D] = ds > 0.f ? sMxv[(e0 + el) / D - glo] + __logf(ds) : -INFINITY;
         }
       }
       DEC_RT(8);
@@ -897,7 +907,8 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ part_o, float* __restrict__ part_lse,
                                                            uint16_t* __restrict__ out, int HQ, int S,
                                                            int* __restrict__ seq_lens, const int* __restrict__ bmap,
-                                                           int G, int append, int lens_by_row, int reserved) {
+                                                           int G, int append, int lens_by_row, int reserved,
+                                                           float* __restrict__ lse_out) {
   // The partials live in the same workspace the in-launch merge uses as zero-means-empty mailboxes, so this kernel
   // hands the workspace back the way it got it: every word it consumed is reset to zero.
   constexpr int VPT = D / 64;  // values per lane
@@ -965,8 +976,40 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ 
     const float inv = den > 0.f ? 1.f / den : 0.f;
     const float v = (s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid]) * inv;
     out[((size_t)b * HQ + hq) * D + tid] = to16<T>(v);
+    if (lse_out != nullptr && tid == 0) lse_out[(size_t)b * HQ + hq] = den > 0.f ? M + __logf(den) : -INFINITY;
   }
   for (int s = tid; s < S; s += 256) part_lse[(size_t)(b * S + s) * HQ + hq] = 0.f;
+}
+
+// f-4: merge of W shard results of one decode step (a sequence's KV rows partitioned over W devices, each device ran
+// decode attention over its rows and all-gathered (out, lse)); the LSE rule of the reference's stage 2 (:391-435):
+// out = sum_r exp(lse_r - max) out_r / sum_r exp(lse_r - max).  One thread per 8 output values.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_merge_shards_kernel(const uint16_t* __restrict__ o_all,
+                                                                  const float* __restrict__ lse_all,
+                                                                  uint16_t* __restrict__ out, int W, long rows, int D) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (row, 8-value chunk)
+  const int cpr = D / 8;
+  if (i >= rows * cpr) return;
+  const long row = i / cpr;
+  const int c = (int)(i % cpr);
+  float mx = -INFINITY;
+  for (int r = 0; r < W; ++r) mx = fmaxf(mx, lse_all[(size_t)r * rows + row]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den = 0.f;
+  for (int r = 0; r < W; ++r) {  // fixed order: reproducible
+    const float l = lse_all[(size_t)r * rows + row];
+    if (l == -INFINITY) continue;  // a shard with no rows for this head contributes nothing
+    const float w = __expf(l - mx);
+    den += w;
+    const uint4 u = *reinterpret_cast<const uint4*>(o_all + ((size_t)r * rows + row) * D + 8 * c);
+    const float2 a = unpack2<T>(u.x), b2 = unpack2<T>(u.y), c2 = unpack2<T>(u.z), d2 = unpack2<T>(u.w);
+    acc[0] = fmaf(w, a.x, acc[0]); acc[1] = fmaf(w, a.y, acc[1]); acc[2] = fmaf(w, b2.x, acc[2]); acc[3] = fmaf(w, b2.y, acc[3]);
+    acc[4] = fmaf(w, c2.x, acc[4]); acc[5] = fmaf(w, c2.y, acc[5]); acc[6] = fmaf(w, d2.x, acc[6]); acc[7] = fmaf(w, d2.y, acc[7]);
+  }
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  const uint4 o = make_uint4(pack2<T>(acc[0] * inv, acc[1] * inv), pack2<T>(acc[2] * inv, acc[3] * inv),
+                             pack2<T>(acc[4] * inv, acc[5] * inv), pack2<T>(acc[6] * inv, acc[7] * inv));
+  *reinterpret_cast<uint4*>(out + (size_t)row * D + 8 * c) = o;
 }
 
 constexpr size_t DEC_WS_HEADER = 256;  // bytes: word 0 = in-launch merge error flag; the rest reserved (zero)
@@ -978,6 +1021,7 @@ struct DecodeArgs {
   const int *page_table, *bmap;
   char* ws;
   size_t ws_bytes;
+  float* lse_out;  // optional [B, HQ]: natural-log LSE of every query head over the rows this call saw
   int64_t sk_b, sk_h, sv_b, sv_h;
   int B, HKV, PS, NLP, S, lens_by_row, reserved;
   float scale;
@@ -1051,11 +1095,11 @@ static int launch_fused(const DecodeArgs& a) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, a.st, (const uint16_t*)a.q, a.bmap, a.seq_lens,
                      a.page_table, (const uint16_t*)a.key_new, (const uint16_t*)a.val_new, (uint16_t*)a.kc,
                      (uint16_t*)a.vc, a.HKV, a.PS, a.NLP, a.S, a.scale, a.lens_by_row, a.reserved, a.sk_b, a.sk_h,
-                     a.sv_b, a.sv_h, (uint16_t*)a.out, part_o, part_lse, mailboxes, err_word, mode);
+                     a.sv_b, a.sv_h, (uint16_t*)a.out, part_o, part_lse, mailboxes, err_word, mode, a.lse_out);
   if (mode == 1)
     hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(a.B * HQ), dim3(256), 0, a.st, part_o, part_lse,
                        (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, a.key_new != nullptr ? 1 : 0, a.lens_by_row,
-                       a.reserved);
+                       a.reserved, a.lse_out);
   return check_launch();
 }
 
@@ -1076,7 +1120,7 @@ static int launch_fallback(const DecodeArgs& a) {
                      (const uint16_t*)a.kc, (const uint16_t*)a.vc, (uint16_t*)a.out, part_o, part_lse, a.seq_lens,
                      a.page_table, a.bmap, a.HKV, a.PS, a.NLP, a.S, a.scale, a.lens_by_row);
   hipLaunchKernelGGL((decode_stage2_kernel<T, D>), dim3(a.B * HQ), dim3(256), 0, a.st, part_o, part_lse,
-                     (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, 0, a.lens_by_row, a.reserved);
+                     (uint16_t*)a.out, HQ, a.S, a.seq_lens, a.bmap, G, 0, a.lens_by_row, a.reserved, a.lse_out);
   return check_launch();
 }
 
@@ -1129,6 +1173,7 @@ static int decode_common(DecodeArgs a, int HQ, int D, int dtype, size_t workspac
   if (a.S > 1 && (!a.ws || workspace_bytes < cvllm_decode_workspace_bytes(a.B, HQ, D, a.S))) return CVLLM_ERR_WORKSPACE;
   a.ws_bytes = workspace_bytes;
   if (a.key_new && D > 128) return CVLLM_ERR_SHAPE;  // fused append exists in the ring kernel only
+  if (a.lse_out && D > 128) return CVLLM_ERR_SHAPE;  // the LSE output too
   const int G = HQ / a.HKV;
   if (dtype == CVLLM_F16) return dispatch_d<F16>(D, G, a);
   if (dtype == CVLLM_BF16) return dispatch_d<BF16>(D, G, a);
@@ -1147,6 +1192,42 @@ extern "C" int cvllm_decode_attn(const void* q, const void* k_cache, const void*
   a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 0;
   a.reserved = -1; a.scale = sm_scale; a.st = (hipStream_t)stream;
   return decode_common(a, HQ, D, dtype, workspace_bytes);
+}
+
+// decode attention that also returns the natural-log LSE of every query head over the rows it saw: one shard of a
+// cross-device split-KV decode; merged with cvllm_decode_merge_shards after the all-gather
+extern "C" int cvllm_decode_attn_lse(const void* q, const void* k_cache, const void* v_cache, void* out, float* lse_out,
+                                     const int32_t* seq_lens_bh, const int32_t* page_table,
+                                     const int32_t* batch_mapping, void* workspace, size_t workspace_bytes, int B,
+                                     int HQ, int HKV, int D, int page_size, int n_logical_pages_max, float sm_scale,
+                                     int n_splits, int dtype, cvllm_stream_t stream) {
+  if (!lse_out) return CVLLM_ERR_ARG;
+  DecodeArgs a{};
+  a.q = q; a.kc = (void*)k_cache; a.vc = (void*)v_cache; a.out = out; a.lse_out = lse_out;
+  a.seq_lens = (int*)seq_lens_bh;
+  a.page_table = page_table; a.bmap = batch_mapping; a.ws = (char*)workspace;
+  a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 0;
+  a.reserved = -1; a.scale = sm_scale; a.st = (hipStream_t)stream;
+  return decode_common(a, HQ, D, dtype, workspace_bytes);
+}
+
+extern "C" int cvllm_decode_merge_shards(const void* out_all, const float* lse_all, void* out, int n_shards, int B,
+                                         int HQ, int D, int dtype, cvllm_stream_t stream) {
+  if (!out_all || !lse_all || !out) return CVLLM_ERR_ARG;
+  if (n_shards <= 0 || B <= 0 || HQ <= 0 || D <= 0 || D % 8) return CVLLM_ERR_ARG;
+  const long rows = (long)B * HQ;
+  const long n = rows * (D / 8);
+  const int blocks = (int)((n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVLLM_F16)
+    hipLaunchKernelGGL(decode_merge_shards_kernel<F16>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)out_all, lse_all,
+                       (uint16_t*)out, n_shards, rows, D);
+  else if (dtype == CVLLM_BF16)
+    hipLaunchKernelGGL(decode_merge_shards_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)out_all, lse_all,
+                       (uint16_t*)out, n_shards, rows, D);
+  else
+    return CVLLM_ERR_SHAPE;
+  return check_launch();
 }
 
 // Fused decode step of the boundary orchestrator (cv/layers/attention.py:127-160 decode branch): append the new

@@ -63,6 +63,20 @@ int cvllm_decode_attn(const void* q, const void* k_cache, const void* v_cache, v
                       int B, int HQ, int HKV, int D, int page_size, int n_logical_pages_max,
                       float sm_scale, int n_splits, int dtype, cvllm_stream_t stream);
 
+/* ---- f-4: one shard of a cross-device split-KV decode ----------------------------------------------------
+ * A single very long sequence's rows are partitioned over W devices (each holds a slice of every (layer, head) in its
+ * own paged cache).  Every device calls cvllm_decode_attn_lse on its slice: out[B,HQ,D] as cvllm_decode_attn plus
+ * lse_out[B,HQ] fp32 = natural-log LSE of the scaled logits over the rows it saw (-inf when it saw none); the
+ * (out, lse) pairs are all-gathered (RCCL over xGMI: W * B*HQ*(2D+4) bytes per layer) and merged with the LSE rule of
+ * attention/sparse_decode_kernel.py:391-435 by cvllm_decode_merge_shards: out_all[W,B,HQ,D], lse_all[W,B,HQ].  */
+int cvllm_decode_attn_lse(const void* q, const void* k_cache, const void* v_cache, void* out, float* lse_out,
+                          const int32_t* seq_lens_bh, const int32_t* page_table,
+                          const int32_t* batch_mapping, void* workspace, size_t workspace_bytes, int B,
+                          int HQ, int HKV, int D, int page_size, int n_logical_pages_max, float sm_scale,
+                          int n_splits, int dtype, cvllm_stream_t stream);
+int cvllm_decode_merge_shards(const void* out_all, const float* lse_all, void* out, int n_shards, int B, int HQ,
+                              int D, int dtype, cvllm_stream_t stream);
+
 /* Fused decode step of the boundary orchestrator: replaces the decode branch of layers/attention.py:127-160
  * (index_select of the lengths, decode_store_kv, head_sparse_decode_attention, index_copy_ back) in one call.
  * bh_seq_lens is the LAYER's full [Bmax+1,HKV] table (indexed by batch_mapping[b]), updated in place;

@@ -515,3 +515,40 @@ def qkv_producer(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tens
     cs = cos_sin[positions.long()].unsqueeze(1)  # [N, 1, D]
     cos, sin = cs.chunk(2, dim=-1)
     return apply_rope(q, cos, sin), apply_rope(k, cos, sin), v, k
+
+
+# --------------------------------------------------------------------------------------------
+# f-4  split-KV decode across devices: per-shard (out, lse) and the LSE merge
+#   (cv/attention/sparse_decode_kernel.py:246-388 stage 1 of ONE split, :391-435 stage 2)
+# --------------------------------------------------------------------------------------------
+def decode_attention_lse(q, k_cache, v_cache, seq_lens_bh, page_table, batch_mapping, HKV: int, PAGE_SIZE: int,
+                         sm_scale: Optional[float] = None):
+    """(out [B,HQ,D] q.dtype, lse [B,HQ] fp32): attention over the rows this shard holds and the natural-log LSE of
+    its scaled logits (-inf, and zero output, where it holds no row) - what stage 1 hands to stage 2 (:355-372)."""
+    B, HQ, D = q.shape
+    G = HQ // HKV
+    scale = 1.0 / math.sqrt(D) if sm_scale is None else float(sm_scale)
+    out = torch.zeros((B, HQ, D), dtype=F32)
+    lse = torch.full((B, HQ), NEG_INF, dtype=F32)
+    for b in range(B):
+        bt = int(batch_mapping[b])
+        for g in range(HKV):
+            L = int(seq_lens_bh[b, g])
+            if L == 0:
+                continue
+            rows = cache_rows(page_table[bt, g], L, PAGE_SIZE)
+            logits = (q[b, g * G : (g + 1) * G].to(F32) @ k_cache[rows].to(F32).T) * scale
+            out[b, g * G : (g + 1) * G] = torch.softmax(logits, -1) @ v_cache[rows].to(F32)
+            lse[b, g * G : (g + 1) * G] = torch.logsumexp(logits, -1)
+    return out.to(q.dtype), lse
+
+
+def merge_shards(out_all: torch.Tensor, lse_all: torch.Tensor) -> torch.Tensor:
+    """out_all [W,B,HQ,D], lse_all [W,B,HQ] -> sum_r exp(lse_r - max) out_r / sum_r exp(lse_r - max) (:391-435);
+    rows no shard has anything for come out zero."""
+    mx = lse_all.max(dim=0, keepdim=True).values
+    w = torch.where(torch.isfinite(lse_all), torch.exp(lse_all - torch.where(torch.isfinite(mx), mx, torch.zeros_like(mx))),
+                    torch.zeros_like(lse_all))
+    den = w.sum(0)
+    num = (w[..., None] * out_all.to(F32)).sum(0)
+    return torch.where(den[..., None] > 0, num / den[..., None].clamp_min(1e-38), torch.zeros_like(num)).to(out_all.dtype)
