@@ -637,6 +637,7 @@ constexpr size_t LV_FUSED_SMEM =
 // =====================================================================================================
 constexpr int SK_TILE = 128;
 constexpr int SK_MAXQB = 8;  // 32-row query blocks (w*G <= 256)
+constexpr int SK_TPW = 4;    // consecutive key tiles per workgroup (Q fragments loaded once, next K tile prefetched)
 template <typename T, int D, int G, bool PASS2>
 __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                      int64_t sq_n, int64_t sk_n, int64_t sk_h,
@@ -647,169 +648,198 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
                                                      int pool) {
   constexpr int KS = D / 16;
   constexpr int CH = D / 8;
+  constexpr int KPT = SK_TILE * CH / 256;  // 16-byte chunks of a K tile per thread
   __shared__ __attribute__((aligned(16))) char s_k[SK_TILE * 256];
   __shared__ float s_col[4][SK_TILE];
   __shared__ float s_lse[SK_MAXQB * 32];
 
+  const int ngrp_max = (ntile_max + SK_TPW - 1) / SK_TPW;
   const int bid = blockIdx.x;
   const int g = bid % HKV;
-  const int tile = (bid / HKV) % ntile_max;
-  const int b = bid / (HKV * ntile_max);
+  const int grp = (bid / HKV) % ngrp_max;
+  const int b = bid / (HKV * ngrp_max);
   const int kb0 = cu_k[b], Lk = cu_k[b + 1] - kb0;
   const int qend = cu_q[b + 1];
   const int keff = Lk - w;  // keys that are scored
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int HQ = HKV * G;
-  (void)HQ;
   if (keff <= 0) {  // L <= w: every key is "recent" -> +inf (the reference leaves these rows uninitialised)
-    if (PASS2 && tile == 0)
+    if (PASS2 && grp == 0)
       for (int i = tid; i < Lk; i += 256) scores[(size_t)(kb0 + i) * HKV + g] = INFINITY;
     return;
   }
-  const int t0 = tile * SK_TILE;
   const int ntile = (keff + SK_TILE - 1) / SK_TILE;
-  if (tile >= ntile) return;
-  const int M = min(SK_TILE, keff - t0);
+  const int tile0 = grp * SK_TPW, tile1 = min(ntile, tile0 + SK_TPW);
+  if (tile0 >= ntile) return;
   const int rows_b = w * G;
   const int nqb = (rows_b + 31) / 32;
 
-  for (int e = tid; e < SK_TILE * CH; e += 256) {
-    const int row = e / CH, ch = e % CH;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (row < M) val = *reinterpret_cast<const uint4*>(k + (size_t)(kb0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
-    *reinterpret_cast<uint4*>(s_k + ktile_off(row, ch)) = val;
-  }
+  uint4 kreg[KPT];
+  auto gload = [&](int tile) {
+    const int t0 = tile * SK_TILE, M = min(SK_TILE, keff - t0);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int e = tid + 256 * j, row = e / CH, ch = e % CH;
+      kreg[j] = make_uint4(0, 0, 0, 0);
+      if (row < M) kreg[j] = *reinterpret_cast<const uint4*>(k + (size_t)(kb0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int e = tid + 256 * j;
+      *reinterpret_cast<uint4*>(s_k + ktile_off(e / CH, e % CH)) = kreg[j];
+    }
+  };
+  gload(tile0);
   if (PASS2) {
-    // exact lse of every window row: reduced over the tiles ONCE per (b, g) by snapkv_lse_kernel (every workgroup
-    // redoing that 256-step reduction was 160 of this pass's 192 us at 32 K keys)
+    // exact lse of every window row: reduced over the tiles ONCE per (b, g) by snapkv_lse_kernel
     const float* lp = lse + ((size_t)b * HKV + g) * (SK_MAXQB * 32);
     for (int row = tid; row < nqb * 32; row += 256) s_lse[row] = row < rows_b ? lp[row] : INFINITY;
   }
-  __syncthreads();
-
-  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int qb = wave; qb < nqb; qb += 4) {
-    // window row -> (query offset, local head): row = qoff*G + hq_local (snapkv.py:109-113)
-    const int row = qb * 32 + r;
+  // this wave's query blocks (qb = wave, wave + 4): fragments stay in registers for all tiles of the workgroup
+  s16x8 qf[2][KS];
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq) {
+    const int row = (wave + 4 * jq) * 32 + r;  // window row -> (query offset, local head): row = qoff*G + hq_local
     const bool valid_q = row < rows_b;
     const int qoff = row / G, hql = row % G;
-    s16x8 qf[KS];
-    {
-      const uint16_t* qp = q + (size_t)(qend - w + (valid_q ? qoff : 0)) * sq_n + (size_t)(g * G + hql) * D + 8 * h;
+    const uint16_t* qp = q + (size_t)(qend - w + (valid_q ? qoff : 0)) * sq_n + (size_t)(g * G + hql) * D + 8 * h;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
-        qf[s] = __builtin_bit_cast(s16x8, t);
-      }
-    }
-    if (!PASS2) {
-      float mx = -INFINITY;
-      f32x16 acc[4];
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-          acc[kb] = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[s], acc[kb]);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const float val = kk < M ? acc[kb][i] * scale_log2e : -INFINITY;
-          acc[kb][i] = val;
-          mx = fmaxf(mx, val);
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(acc[kb][i] - mx);
-      sum += __shfl_xor(sum, 32, 64);
-      if (h == 0 && valid_q) {
-        float* pp = part + ((((size_t)b * HKV + g) * ntile_max + tile) * (SK_MAXQB * 32) + row) * 2;
-        pp[0] = mx;
-        pp[1] = sum;
-      }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        f32x16 a2;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a2[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-          a2 = mfma32s<T>(qf[s], __builtin_bit_cast(s16x8, a), a2);
-        }
-        float cs = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int qrow = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          cs += __builtin_amdgcn_exp2f(a2[i] * scale_log2e - s_lse[qrow]);
-        }
-        colsum[kb] += cs;
-      }
+    for (int s = 0; s < KS; ++s) {
+      uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+      qf[jq][s] = __builtin_bit_cast(s16x8, t);
     }
   }
-  if (PASS2) {
+  lstore();
+  __syncthreads();
+
+  for (int tile = tile0; tile < tile1; ++tile) {
+    if (tile + 1 < tile1) gload(tile + 1);  // in flight under this tile's MFMAs
+    const int t0 = tile * SK_TILE, M = min(SK_TILE, keff - t0);
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const float v = colsum[kb] + __shfl_xor(colsum[kb], 32, 64);
-      if (h == 0) s_col[wave][kb * 32 + r] = v;
+    for (int jq = 0; jq < 2; ++jq) {
+      const int qb = wave + 4 * jq;
+      if (qb >= nqb) continue;  // wave-uniform
+      const int row = qb * 32 + r;
+      const bool valid_q = row < rows_b;
+      if (!PASS2) {
+        float mx = -INFINITY;
+        f32x16 acc[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+            acc[kb] = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[jq][s], acc[kb]);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float val = kk < M ? acc[kb][i] * scale_log2e : -INFINITY;
+            acc[kb][i] = val;
+            mx = fmaxf(mx, val);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(acc[kb][i] - mx);
+        sum += __shfl_xor(sum, 32, 64);
+        if (h == 0 && valid_q) {
+          float* pp = part + ((((size_t)b * HKV + g) * ntile_max + tile) * (SK_MAXQB * 32) + row) * 2;
+          pp[0] = mx;
+          pp[1] = sum;
+        }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          f32x16 a2;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) a2[i] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+            a2 = mfma32s<T>(qf[jq][s], __builtin_bit_cast(s16x8, a), a2);
+          }
+          float cs = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int qrow = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            cs += __builtin_amdgcn_exp2f(a2[i] * scale_log2e - s_lse[qrow]);
+          }
+          colsum[kb] += cs;
+        }
+      }
     }
-    __syncthreads();
-    if (tid < SK_TILE) s_col[0][tid] = s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid];
-    __syncthreads();
-    if (tid < M) {
-      // causal avg-pool, kernel `pool`, clipped at the tile start (snapkv.py:253-262 with BLOCK_K = 128)
-      const int lo = max(0, tid - (pool - 1));
-      float t = 0.f;
-      for (int j = lo; j <= tid; ++j) t += s_col[0][j];
-      scores[(size_t)(kb0 + t0 + tid) * HKV + g] = t / (float)(tid - lo + 1);
+    if (PASS2) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const float v = colsum[kb] + __shfl_xor(colsum[kb], 32, 64);
+        if (h == 0) s_col[wave][kb * 32 + r] = v;
+      }
+      __syncthreads();
+      if (tid < SK_TILE) s_col[0][tid] = s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid];
+      __syncthreads();
+      if (tid < M) {
+        // causal avg-pool, kernel `pool`, clipped at the tile start (snapkv.py:253-262 with BLOCK_K = 128)
+        const int lo = max(0, tid - (pool - 1));
+        float t = 0.f;
+        for (int j = lo; j <= tid; ++j) t += s_col[0][j];
+        scores[(size_t)(kb0 + t0 + tid) * HKV + g] = t / (float)(tid - lo + 1);
+      }
+      if (tile == 0)  // last w keys <- +inf (snapkv.py:267-276)
+        for (int i = tid; i < w; i += 256) scores[(size_t)(kb0 + keff + i) * HKV + g] = INFINITY;
     }
-    if (tile == 0)  // last w keys <- +inf (snapkv.py:267-276)
-      for (int i = tid; i < w; i += 256) scores[(size_t)(kb0 + keff + i) * HKV + g] = INFINITY;
+    __syncthreads();  // every read of this K tile (and of s_col) is done
+    if (tile + 1 < tile1) {
+      lstore();
+      __syncthreads();
+    }
   }
 }
 
 // lse[b, g, row] = log2-domain log-sum-exp of window row `row` over all scored keys, from the per-tile (max, sum)
 // partials of pass 1.  One workgroup per (b, g); thread = (row, slice of the tiles); slices meet in LDS.
-constexpr int SK_LSE_SLICES = 4;
-__global__ __launch_bounds__(SK_MAXQB * 32 * SK_LSE_SLICES) void snapkv_lse_kernel(
+constexpr int SK_LSE_SLICES = 16;
+constexpr int SK_LSE_ROWS = 64;  // window rows per workgroup
+__global__ __launch_bounds__(SK_LSE_ROWS * SK_LSE_SLICES) void snapkv_lse_kernel(
     const float* __restrict__ part, float* __restrict__ lse, const int* __restrict__ cu_k, int HKV, int w, int G,
     int ntile_max) {
   constexpr int ROWS = SK_MAXQB * 32;
-  __shared__ float s_m[SK_LSE_SLICES][ROWS], s_s[SK_LSE_SLICES][ROWS];
-  const int bg = blockIdx.x, b = bg / HKV;
-  const int row = threadIdx.x % ROWS, sl = threadIdx.x / ROWS;
+  __shared__ float s_m[SK_LSE_SLICES][SK_LSE_ROWS], s_s[SK_LSE_SLICES][SK_LSE_ROWS];
+  const int bg = blockIdx.x / (ROWS / SK_LSE_ROWS), b = bg / HKV;
+  const int rl = threadIdx.x % SK_LSE_ROWS, sl = threadIdx.x / SK_LSE_ROWS;
+  const int row = (blockIdx.x % (ROWS / SK_LSE_ROWS)) * SK_LSE_ROWS + rl;
   const int keff = cu_k[b + 1] - cu_k[b] - w;
   const int ntile = keff > 0 ? (keff + SK_TILE - 1) / SK_TILE : 0;
   const int rows_b = w * G;
   float m = -INFINITY, ssum = 0.f;
   if (row < rows_b) {
     const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)bg * ntile_max * ROWS + row;
-    for (int t = sl; t < ntile; t += SK_LSE_SLICES) {
+#pragma unroll 4
+    for (int t = sl; t < ntile; t += SK_LSE_SLICES) {  // a slice folds its tiles in tile order (fixed: reproducible)
       const float2 ms = pp[(size_t)t * ROWS];
       const float mn = fmaxf(m, ms.x);
       ssum = ssum * __builtin_amdgcn_exp2f(m - mn) + ms.y * __builtin_amdgcn_exp2f(ms.x - mn);
       m = mn;
     }
   }
-  s_m[sl][row] = m;
-  s_s[sl][row] = ssum;
+  s_m[sl][rl] = m;
+  s_s[sl][rl] = ssum;
   __syncthreads();
   if (sl == 0 && row < rows_b) {
-    float M = s_m[0][row];
+    float M = s_m[0][rl];
 #pragma unroll
-    for (int i = 1; i < SK_LSE_SLICES; ++i) M = fmaxf(M, s_m[i][row]);
+    for (int i = 1; i < SK_LSE_SLICES; ++i) M = fmaxf(M, s_m[i][rl]);
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < SK_LSE_SLICES; ++i) tot += s_s[i][row] * __builtin_amdgcn_exp2f(s_m[i][row] - M);
+    for (int i = 0; i < SK_LSE_SLICES; ++i) tot += s_s[i][rl] * __builtin_amdgcn_exp2f(s_m[i][rl] - M);
     lse[(size_t)bg * ROWS + row] = M + __builtin_amdgcn_logf(tot);
   }
 }
@@ -979,13 +1009,13 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
                     float* part, const int* cu_q, const int* cu_k, int B, int HKV, int w, int ntile, float scale,
                     int pool, hipStream_t st) {
   const float c = scale * 1.4426950408889634f;
-  dim3 grid(B * ntile * HKV), block(256);
+  dim3 grid(B * ((ntile + SK_TPW - 1) / SK_TPW) * HKV), block(256);
   float* lse = part + (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2;
 #define SNAP(G_)                                                                                                      \
   {                                                                                                                   \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,  \
                        sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \
-    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV), dim3(SK_MAXQB * 32 * SK_LSE_SLICES), 0, st,                   \
+    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32 / SK_LSE_ROWS)), dim3(SK_LSE_ROWS* SK_LSE_SLICES), 0, st,                   \
                        (const float*)part, lse, cu_k, HKV, w, G_, ntile);                                             \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
                        sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \

@@ -1,36 +1,52 @@
 #!/bin/bash
-# Round evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r01
-# Writes small summaries into gpurun_out/<round>/ (copy the ones to keep into profiles/).
-set -eo pipefail
-R=${1:-r01}
+# Round evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r02
+# Writes summaries AND the logs of every step into gpurun_out/<round>/ (copy the ones to keep into profiles/; nothing is
+# deleted here but the raw trace directories, whose content the summaries are made from).
+set -o pipefail
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 mkdir -p "$O"
-# 1. kernel trace + the tool's own stats of the bench command
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq > "$O/bench_under_rocprof.log" 2>&1
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq"
+# 1. kernel trace + the tool's own stats of the bench command (C3 through the engine)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- $B > "$O/bench_under_rocprof.log" 2>&1
 python3 tools/prof_summary.py "$O/kt" > "$O/${R}_bench_c3_kernel_summary.txt"
 cp "$(find "$O/kt" -name '*kernel_stats.csv' | head -1)" "$O/${R}_bench_c3_kernel_stats.csv"
 grep "^{\"metric\"" "$O/bench_under_rocprof.log" | tail -1 > "$O/${R}_bench_c3_under_rocprof.json"
 rm -rf "$O/kt"
-echo "[1/6] kernel trace done"
-# 2. HBM traffic of the decode kernel (separate --pmc passes; C3 per-layer decode shape)
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pf" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/pmc_f.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pw" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/pmc_w.log" 2>&1
-python3 tools/pmc_summary.py "$O/pf" "$O/pw" > "$O/${R}_bench_pmc_kernels.json"
-rm -rf "$O/pf" "$O/pw"
-echo "[2/6] decode PMC done"
+echo "[1/7] kernel trace done"
+# 2. HBM traffic of the decode-attention kernel INSIDE bench.py (separate --pmc passes).  Counter collection over every
+#    dispatch of bench.py makes rocprofv3 segfault inside its dispatch callback (with and without HIP graphs; the tiny
+#    workload survives): the collection is therefore limited to the roofline kernel with --kernel-include-regex.
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_fused --kernel-trace --output-format csv -d "$O/pf" -- $B > "$O/pmc_fetch.log" 2>&1
+echo "pmc FETCH_SIZE rc=$?" >> "$O/pmc_fetch.log"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex decode_fused --kernel-trace --output-format csv -d "$O/pw" -- $B > "$O/pmc_write.log" 2>&1
+echo "pmc WRITE_SIZE rc=$?" >> "$O/pmc_write.log"
+python3 tools/pmc_summary.py "$O/pf" "$O/pw" decode_fused > "$O/${R}_bench_pmc_kernels.json"
+# the unfiltered pass, kept as the record of the crash (its log names the faulting frame)
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pall" -- $B > "$O/pmc_unfiltered_crash.log" 2>&1
+echo "unfiltered pmc rc=$?" >> "$O/pmc_unfiltered_crash.log"
+rm -rf "$O/pf" "$O/pw" "$O/pall"
+echo "[2/7] decode PMC done"
 # 3. SQ counters of the prefill kernel (two passes of 8 counters)
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/s1" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq1.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$O/s2" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq2.log" 2>&1
 { echo "prefill_attn_kernel<BF16,128,4>, 1 x 32768 tokens, per launch (SQ counters are in 4-cycle units summed over waves / SIMDs)"; python3 tools/pmc_sq.py "$O/s1" prefill_attn; python3 tools/pmc_sq.py "$O/s2" prefill_attn; } > "$O/${R}_prefill_sq_counters.txt"
 rm -rf "$O/s1" "$O/s2"
-echo "[3/6] prefill SQ counters done"
-# 4. in-kernel phase timestamps of the decode kernel (debug build)
-timeout -k 10 200 python3 tools/decode_ts.py > "$O/${R}_decode_phase_timestamps.txt" 2>&1
-echo "[4/6] decode timestamps done"
-# 5. stand-alone kernel timings
-{ python3 tools/microbench.py prefill --L 16384; python3 tools/microbench.py prefill --L 32768; python3 tools/microbench.py decode --L 16640 --splits 32; python3 tools/microbench.py decode --L 65536 --B 8 --splits 4; python3 tools/microbench.py scoring --L 32768; } > "$O/${R}_microbench.txt" 2>&1
-echo "[5/6] microbench done"
+echo "[3/7] prefill SQ counters done"
+# 4. per-workgroup phase stamps of the decode kernel on one clock (debug build; back-to-back launches)
+timeout -k 10 200 python3 tools/decode_rt.py > "$O/${R}_decode_phase_stamps.txt" 2>&1
+echo "[4/7] decode stamps done"
+# 5. stand-alone kernel timings; decode with the in-launch merge and with the two-kernel merge on the same box
+{ python3 tools/microbench.py prefill --L 16384; python3 tools/microbench.py prefill --L 32768;
+  echo "# decode attention, C3 per-layer shape, in-launch split merge (default):"; python3 tools/microbench.py decode --L 16640 --splits 32;
+  echo "# same, CVLLM_DECODE_MERGE=two-kernel (stage 1 + decode_stage2_kernel):"; CVLLM_DECODE_MERGE=two-kernel python3 tools/microbench.py decode --L 16640 --splits 32;
+  python3 tools/microbench.py decode --L 65536 --B 8 --splits 4; python3 tools/microbench.py scoring --L 32768; } > "$O/${R}_microbench.txt" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/ktm.log" 2>&1
+CVLLM_DECODE_MERGE=two-kernel timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm2" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/ktm2.log" 2>&1
+{ echo "# rocprofv3 --kernel-trace of tools/microbench.py decode --L 16640 --splits 32 (9 caches back to back in a HIP graph)"; echo "# in-launch merge:"; python3 tools/prof_summary.py "$O/ktm" decode; echo "# CVLLM_DECODE_MERGE=two-kernel:"; python3 tools/prof_summary.py "$O/ktm2" decode; } > "$O/${R}_decode_kernel_durations.txt"
+rm -rf "$O/ktm" "$O/ktm2"
+echo "[5/7] microbench done"
 # 6. the bench lines: default run (C3, with cpu_baseline), C2, C4
 python3 bench.py > "$O/bench_c3.log" 2>&1
 grep "^{\"metric\"" "$O/bench_c3.log" | tail -1 > "$O/${R}_bench_c3.json"
@@ -38,11 +54,11 @@ python3 bench.py --workload C2 --steps 2 --warmup 1 --no-cpu-baseline > "$O/benc
 grep "^{\"metric\"" "$O/bench_c2.log" | tail -1 > "$O/${R}_bench_c2.json"
 python3 bench.py --workload C4 --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench_c4.log" 2>&1
 grep "^{\"metric\"" "$O/bench_c4.log" | tail -1 > "$O/${R}_bench_c4.json"
-echo "[6/6] bench lines done"
+echo "[6/7] bench lines done"
 # 7. optional (COLLECT_C5=1, ~3 min): one GPU's share of BASELINE.json configs[4] - 8 sequences of 128K context
 if [ "${COLLECT_C5:-0}" = "1" ]; then
   python3 bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline > "$O/bench_c5.log" 2>&1
   grep "^{\"metric\"" "$O/bench_c5.log" | tail -1 > "$O/${R}_bench_c5_per_gpu.json"
+  echo "[7/7] C5 share done"
 fi
-rm -f "$O"/*.log
 ls -la "$O"
