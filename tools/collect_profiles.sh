@@ -22,7 +22,8 @@ timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_fused
 echo "pmc FETCH_SIZE rc=$?" >> "$O/pmc_fetch.log"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex decode_fused --kernel-trace --output-format csv -d "$O/pw" -- $B > "$O/pmc_write.log" 2>&1
 echo "pmc WRITE_SIZE rc=$?" >> "$O/pmc_write.log"
-python3 tools/pmc_summary.py "$O/pf" "$O/pw" decode_fused > "$O/${R}_bench_pmc_kernels.json"
+ALG=$(python3 -c "import json,sys;print(json.load(open('$O/${R}_bench_c3_under_rocprof.json'))['roofline']['algorithmic_bytes_per_launch'])")
+python3 tools/pmc_summary.py "$O/pf" "$O/pw" decode_fused --command "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-include-regex decode_fused --kernel-trace -- $B" --workload C3 --alg-bytes "$ALG" > "$O/${R}_bench_pmc.json"
 # the unfiltered pass, kept as the record of the crash (its log names the faulting frame)
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pall" -- $B > "$O/pmc_unfiltered_crash.log" 2>&1
 echo "unfiltered pmc rc=$?" >> "$O/pmc_unfiltered_crash.log"
