@@ -20,7 +20,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # prefill_attn.hip: row maxima over MFMA results; with NaNs honoured hipcc canonicalises every operand (v_max x,x)
 # decode_attn.hip: first kernel arguments preloaded into SGPRs at wave launch (the decode kernel's fixed cost is a
 # chain of dependent memory round trips; the kernarg fetch is the first of them)
-FILE_FLAGS = {"prefill_attn.hip": ["-fno-honor-nans"],
+# prefill_attn.hip, 4-wave kernel: MFMA results in arch VGPRs (hipcc otherwise selects the ACC-register form for a kernel
+# allowed more than 256 registers and copies every logit back with v_accvgpr_read), and no SLP vectorisation (it pairs
+# the row-sum adds of the two query blocks into v_pk_add_f32 and moves them out of their hand-placed MFMA shadows)
+FILE_FLAGS = {"prefill_attn.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
               "decode_attn.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 
 

@@ -67,15 +67,16 @@ __device__ __forceinline__ uint16_t to16<BF16>(float x) {
 // instead of two conversions and an OR)
 template <typename T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 template <>
 __device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
-  half2_t v = {(_Float16)lo, (_Float16)hi};
-  return __builtin_bit_cast(uint32_t, v);
+  const f32x2_t f = {lo, hi};  // ONE vector conversion: selected as v_cvt_pk_f16_f32 whatever the SLP vectoriser does
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2_t));
 }
 template <>
 __device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
-  bf162_t v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(uint32_t, v);
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf162_t));
 }
 template <typename T>
 __device__ __forceinline__ float from16(uint16_t b);
@@ -104,6 +105,19 @@ int store_decode_kv_impl(const void* key, const void* value, int64_t sk_b, int64
                          const int32_t* batch_mapping, int32_t* bh_lens, const int32_t* page_table, void* k_cache,
                          void* v_cache, int B, int HKV, int D, int page_size, int n_logical_pages_max,
                          int reserved_batch, int dtype, int lens_by_row, cvllm_stream_t stream);
+
+// dynamic-LDS limit of a kernel, set once per (kernel instantiation, device): the attribute lives on the device's
+// code object, so a second device in the same process needs its own call
+template <typename K>
+static void set_dyn_lds_once(K kern, int bytes) {
+  static bool done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !done[dev]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev >= 0 && dev < 64) done[dev] = true;
+  }
+}
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? CVLLM_OK : CVLLM_ERR_LAUNCH; }
 

@@ -1060,17 +1060,6 @@ static bool merge_in_launch_allowed() {
   return v == 1;
 }
 
-template <typename K>
-static void set_dyn_lds_once(K kern, int bytes) {  // per device: the attribute lives on the device's code object
-  static bool done[64] = {false};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !done[dev]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (dev >= 0 && dev < 64) done[dev] = true;
-  }
-}
-
 template <typename T, int D, int G>
 static int launch_fused(const DecodeArgs& a) {
   constexpr int NW = 4, NL = 4, R = 4;

@@ -24,6 +24,8 @@
 // heaviest (last) query tiles first for causal load balance.
 #include "common.h"
 
+#include <type_traits>
+
 namespace cvllm {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -375,6 +377,539 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
 }
 
 
+// =====================================================================================================================
+// 4-wave structure (D = 128, page size a multiple of 64): one wave per SIMD, 64 query rows per wave.
+//
+// Why a second structure: with 32 rows per wave (kernel above) every wave re-reads the whole K and V tile from LDS for
+// 32 MFMAs' worth of work, and the two waves of a SIMD, released by the same barrier, contend for the one vector-issue
+// port in lock-step (SQ counters, round 2: 31 % of wave cycles parked, 32 % issue-stalled, matrix pipe 50 % busy).
+// Here a wave owns TWO 32-row query blocks: every K / V fragment read from LDS feeds two MFMAs (half the LDS bytes
+// per flop), there is no co-resident wave, and the wave's own softmax VALU work is hand-placed into the 32-cycle
+// shadows of its own MFMAs (see the loop).  What bounds it: with one wave per SIMD EVERY instruction - VALU, scalar,
+// LDS, wait - takes an issue slot (>= 4 cycles) from the same in-order stream; a 64-key tile is 64 MFMAs (2048
+// cycles of matrix pipe) and ~570 instructions (~2700 issue cycles), measured 4100 cycles per tile.
+//   * workgroup = 4 waves = the same 256 rows ((256/G) tokens x G heads of one kv-head) as above, same grid order;
+//   * registers: O 128, Q fragments 64, two 32-key logit blocks 64, P 16, staging 2 x 32, fragment rings 32 (~390);
+//   * K/V tiles come in by buffer loads (tile base and valid bytes in the resource descriptor, lane-constant VGPR
+//     offsets: no per-load address arithmetic, rows past the end of the tile read as zero), issued two tiles before
+//     their LDS writes, three LDS buffers each for K and V;
+//   * same LDS images and fragment addressing as the 8-wave kernel; the softmax differs in two documented ways: the
+//     running max is updated per 32-key unit (not per 64-key tile) and follows the row max only after it has grown
+//     by more than P4_THR (deferred rescale).  Both kernels meet the attention tolerance against the oracle
+//     (tests/test_gpu_prefill.py runs every case on both).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// tunables (A/B builds pass -D): VALU issue cycles of exp work dealt to one MFMA shadow; rescale threshold (exp2 domain)
+#ifndef P4_CAP
+#define P4_CAP 24
+#endif
+#ifndef P4_THR
+#define P4_THR 8
+#endif
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// First exp micro-op (of 112: see `micro` in the kernel) of MFMA slot k of a unit: ops are dealt in order, a slot takes
+// ops while their issue costs (fma / add / pack 4 cycles, exp2 8) fit P4_CAP; everything is placed by slot 24, where the
+// second half of P is first needed.
+__host__ __device__ constexpr int p4_mb(int k) {
+  int g = 0;
+  for (int slot = 0; slot < k && slot < 24; ++slot) {
+    int used = 0;
+    while (g < 112) {
+      const int op = g < 4 ? g : ((g - 4) / 7 == 15 ? 4 + (g - 4) % 7 : (g - 4) % 7);
+      const int cost = (op == 2 || op == 3) ? 8 : 4;
+      if (used + cost > P4_CAP && slot != 23) break;
+      used += cost;
+      ++g;
+    }
+  }
+  return k >= 24 ? 112 : g;
+}
+static_assert(p4_mb(0) == 0 && p4_mb(24) == 112, "exp micro-op placement");
+static_assert(p4_mb(16) >= 4 + 7 * 7 + 7, "P of keys 0-15 must be complete before the first PV MFMA");
+constexpr int P4_THREADS = 256;
+constexpr int P4_SMEM = 3 * PF_KTILE + 3 * PF_VTILE;  // K and V triple-buffered: 113,664 B
+static_assert(P4_SMEM >= 4 * 64 * PF_OSTRIDE, "O staging image must fit");
+
+
+template <typename T, int G>
+__global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void prefill_attn_w4_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, int64_t sq_n,
+    int64_t sk_n, int64_t sk_h, int64_t sv_n, int64_t sv_h, const uint16_t* __restrict__ kc,
+    const uint16_t* __restrict__ vc, uint16_t* __restrict__ out, const int* __restrict__ seq_lens,
+    const int* __restrict__ page_table, const int* __restrict__ bmap, const int* __restrict__ cu, int B, int HKV,
+    int PS, int NLP, float scale_log2e) {
+  constexpr int D = 128;
+  constexpr int BM = PF_ROWS / G;  // tokens per query tile
+  constexpr int KS = D / 16;       // k-steps of the QK^T product
+  constexpr int DB = D / 32;       // 32-wide blocks of the head dim
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int bid = blockIdx.x;
+  const int g = bid % HKV;
+  const int b = (bid / HKV) % B;
+  const int tile_rev = bid / (HKV * B);
+  const int s0 = cu[b];
+  const int La = cu[b + 1] - s0;
+  const int nqt = (La + BM - 1) / BM;
+  if (tile_rev >= nqt) return;
+  const int qt = nqt - 1 - tile_rev;  // heaviest tiles first
+  const int m0 = qt * BM;
+  const int HQ = HKV * G;
+
+  const int Lc = seq_lens[b * HKV + g];
+  const int* pt = page_table + ((size_t)bmap[b] * HKV + g) * NLP;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- the wave's two query blocks: rows wave*64 + 32*qb + r -----------------------------------------------------
+  int tok[2];
+  s16x8 qf[2][KS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = wave * 64 + qb * 32 + r;
+    const int head_local = row / BM;
+    tok[qb] = m0 + row % BM;
+    const bool valid_q = tok[qb] < La;
+    const uint16_t* qp = q + (size_t)(s0 + (valid_q ? tok[qb] : 0)) * sq_n + (size_t)(g * G + head_local) * D + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+      qf[qb][s] = __builtin_bit_cast(s16x8, t);
+    }
+  }
+
+  const int ntc = (Lc + PF_KT - 1) / PF_KT;      // cached-prefix tiles
+  const int la_vis = min(m0 + BM, La);           // appended keys visible to this query tile
+  const int nta = (la_vis + PF_KT - 1) / PF_KT;  // appended tiles (last ones are on the diagonal)
+  const int ntiles = ntc + nta;
+
+  // ---- accumulators and LDS addressing ------------------------------------------------------------------------------
+  f32x16 oacc[2][DB];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[qb][db][i] = 0.f;
+  float m_run[2] = {-1e30f, -1e30f};  // running max (exp2 domain), identical in lanes l and l^32; finite (see chain)
+  float l_run[2] = {0.f, 0.f};        // running sum of this lane's half of the keys
+
+  const int gi = lane >> 4;
+  const int li = lane & 15;
+  const int tq = li >> 2, tp = li & 3;
+  const uint32_t k_lane = r * PF_KSTR + h * 16;
+  const uint32_t v_lane = (4 * (gi >> 1) + tq) * PF_VSTR + (gi & 1) * 32 + tp * 8;
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef __attribute__((address_space(3))) s16x8 lds_s16x8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+  // ---- staging: thread -> rows srow + 16 i (i = 0..3), 16-byte chunk sch of a K and of a V tile -------------------
+  // Buffer loads: the tile's base and size sit in the resource descriptor (SGPRs), the row block in the scalar offset,
+  // the lane's (row, chunk) in ONE loop-invariant VGPR - no per-load address arithmetic on the VALU; rows past the end
+  // of the tile are out of range and read as zero (their logits are masked).  Cached and appended tiles differ only
+  // in scalars, so a tile's 8 loads and 8 LDS writes can be dealt out one by one to MFMA slots without branches.
+  const int sch = tid & 15;
+  const int srow = tid >> 4;  // 0..15
+  u32x4 st[2][8];  // two register sets (K rows 0-3, V rows 4-7), every index a compile-time constant
+  int ld_pi = 0, ld_po = 0;
+  int ld_pg = (ntc > 0) ? pt[0] : 0;
+  // The bounds check of a buffer load covers the VGPR offset only (not the scalar offset), so the row offset lives
+  // in the VGPR - four loop-invariant offsets per tensor, rebuilt once when the tiles change from cached to appended -
+  // and the tile's base and valid byte count in the descriptor.  The two kinds are separate (uniform) branches: with
+  // one wave per SIMD every instruction of any kind takes an issue slot from the MFMAs, and selecting between two
+  // 64-bit address computations per tile cost 80 scalar instructions.
+  uint32_t voffk[4], voffv[4];
+  int voff_kind = -1;  // 0 = cached layout, 1 = appended layout
+  __amdgpu_buffer_rsrc_t rk, rv;
+  auto tile_desc = [&](int tt) __attribute__((always_inline)) {
+    if (tt < ntc) {
+      if (voff_kind != 0) {
+        voff_kind = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voffk[i] = voffv[i] = (uint32_t)(srow + 16 * i) * (D * 2) + sch * 16;
+      }
+      const int count = min(PF_KT, Lc - tt * PF_KT);  // > 0
+      const int64_t rowbase = (int64_t)ld_pg * PS + ld_po;  // int64 row offset (reference :371)
+      rk = __builtin_amdgcn_make_buffer_rsrc((void*)(kc + rowbase * D), 0, count * D * 2, 0x00020000);
+      rv = __builtin_amdgcn_make_buffer_rsrc((void*)(vc + rowbase * D), 0, count * D * 2, 0x00020000);
+      ld_po += PF_KT;
+      if (ld_po >= PS) {
+        ld_po = 0;
+        ld_pi += 1;
+        ld_pg = pt[min(ld_pi, NLP - 1)];
+      }
+    } else {
+      if (voff_kind != 1) {
+        voff_kind = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          voffk[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sk_n * 2 + sch * 16;
+          voffv[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sv_n * 2 + sch * 16;
+        }
+      }
+      const int j0 = (tt - ntc) * PF_KT;
+      const int count = min(PF_KT, la_vis - j0);  // <= 0 for tiles past the last one: nothing is fetched
+      const uint16_t* kg = k + (int64_t)(s0 + j0) * sk_n + (int64_t)g * sk_h;
+      const uint16_t* vg = v + (int64_t)(s0 + j0) * sv_n + (int64_t)g * sv_h;
+      rk = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)kg, 0, count > 0 ? (int)(((uint32_t)(count - 1) * (uint32_t)sk_n + D) * 2) : 0, 0x00020000);
+      rv = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)vg, 0, count > 0 ? (int)(((uint32_t)(count - 1) * (uint32_t)sv_n + D) * 2) : 0, 0x00020000);
+    }
+  };
+  auto gload_piece = [&](int set, int i) __attribute__((always_inline)) {
+    st[set][i] = (i < 4) ? __builtin_amdgcn_raw_buffer_load_b128(rk, voffk[i & 3], 0, 0)
+                         : __builtin_amdgcn_raw_buffer_load_b128(rv, voffv[i & 3], 0, 0);
+  };
+  const uint32_t kst = srow * PF_KSTR + sch * 16, vst = srow * PF_VSTR + sch * 16;
+  auto lstore_piece = [&](int set, int buf, int i) __attribute__((always_inline)) {
+    char* kb = smem + buf * PF_KTILE + kst;
+    char* vb = smem + 3 * PF_KTILE + buf * PF_VTILE + vst;
+    if (i < 4)
+      *reinterpret_cast<u32x4*>(kb + 16 * i * PF_KSTR) = st[set][i];
+    else
+      *reinterpret_cast<u32x4*>(vb + 16 * (i - 4) * PF_VSTR) = st[set][i];
+  };
+
+  // The loop works in UNITS of 32 keys (half a staged tile).  For unit u (logits S(u), 16 registers per query block):
+  //   phase A: 16 MFMAs  S(u+1) = K[unit u+1] Q^T      (every K fragment feeds both query blocks)
+  //   phase B: 16 MFMAs  O^T   += V[unit u]^T P(u)^T   (every V fragment feeds both query blocks)
+  // and the VALU / LDS / memory work is HAND-PLACED into the 32 MFMA shadows of the unit (a slot = one MFMA + its
+  // fillers, closed by sched_barrier(0) so that hipcc keeps the placement; left to itself it forms one VALU lump per
+  // phase, which a single wave per SIMD cannot hide): exp2 / pack / row-sum items of P(u) over phase A and the first
+  // half of phase B (P of keys 16-31 is first needed by the 9th PV MFMA), the row max of S(u+1) and the running-max
+  // bookkeeping over the second half of phase B, the LDS writes of tile t+2 over phase A and the buffer loads of tile
+  // t+3 over phase B of the tile's second unit; fragment reads run two fragments ahead of their MFMAs (rings of 3).
+  // Budget per MFMA: 32 cycles of matrix pipe, 8 of them holding the vector issue port; one item = 2 fma + 2 exp +
+  // 2 add + 1 cvt_pk = 36 issue cycles.  Only two logit blocks (64 registers) are live: with Q (64) and the staging
+  // registers (32) the arch VGPRs hold everything the VALU touches (this file is built with -amdgpu-mfma-vgpr-form:
+  // MFMA results in arch VGPRs, no v_accvgpr_read in front of the softmax) and nothing spills.  K and V are
+  // triple-buffered: S(t+1) of a unit is computed in the same iteration that writes tile t+2.
+  auto k_read = [&](const lds_char* kbp, int s) __attribute__((always_inline)) {
+    return *reinterpret_cast<const lds_s16x8*>(kbp + 32 * s);
+  };
+  auto v_read = [&](const lds_char* vbp, int i) __attribute__((always_inline)) {  // i = 4 * s2 + db
+    const uint32_t a0 = (i >> 2) * 16 * PF_VSTR + 64 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbp + a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbp + a0 + 8 * PF_VSTR));
+    const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return a;
+  };
+  auto k_ptr = [&](int buf, int kb) __attribute__((always_inline)) {
+    uint32_t ka = lds0 + buf * PF_KTILE + kb * (32 * PF_KSTR) + k_lane;
+    asm volatile("" : "+v"(ka));  // one lane-constant VGPR + immediates for every read of the unit
+    return (const lds_char*)(uintptr_t)ka;
+  };
+  auto v_ptr = [&](int buf, int kb) __attribute__((always_inline)) {
+    uint32_t va = lds0 + 3 * PF_KTILE + buf * PF_VTILE + kb * (32 * PF_VSTR) + v_lane;
+    asm volatile("" : "+v"(va));
+    return (const lds_char*)(uintptr_t)va;
+  };
+
+  float psum[2] = {0.f, 0.f}, mx_raw[2] = {-INFINITY, -INFINITY}, mx_new[2] = {0.f, 0.f};
+  bool take[2] = {false, false};
+  u32x4 pw[2][2];   // P fragments of the current unit [query block][keys 0-15 / 16-31]
+  s16x8 kfr[4], vfr[4];  // fragment rings: reads run three fragments ahead of their MFMAs
+
+  // The exp work of a unit as a list of 112 micro-ops, dealt to the unit's first 24 MFMA shadows by issue
+  // cost (p4_mb below).  Item j = 8 s2 + 4 qb + jp turns two logits into two probabilities and one packed word:
+  // ops 0-3 (fma, fma, exp2, exp2) of item b, then ops 4-6 (row-sum add, add, pack) of item b-1 - the adds one item
+  // late, or they would wait out the transcendental unit's latency.  Every op ends in an empty asm anchor: hipcc's
+  // IR passes otherwise sink it to its first use (the PV MFMA, the l update), out of its slot.
+  float me0 = 0.f, me1 = 0.f, mp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  auto micro = [&](const f32x16(&sc_)[2], int g) __attribute__((always_inline)) {
+    const int b = g < 4 ? 0 : 1 + (g - 4) / 7;
+    const int op = g < 4 ? g : (b == 16 ? 4 + (g - 4) % 7 : (g - 4) % 7);
+    const int j = op < 4 ? b : b - 1;
+    const int s2 = j >> 3, qb = (j >> 2) & 1, jp = j & 3;
+    if (op == 0) {
+      me0 = fmaf(sc_[qb][8 * s2 + 2 * jp], scale_log2e, -m_run[qb]);
+      asm volatile("" : "+v"(me0));
+    } else if (op == 1) {
+      me1 = fmaf(sc_[qb][8 * s2 + 2 * jp + 1], scale_log2e, -m_run[qb]);
+      asm volatile("" : "+v"(me1));
+    } else if (op == 2) {
+      mp[j & 1][0] = __builtin_amdgcn_exp2f(me0);
+      asm volatile("" : "+v"(mp[j & 1][0]));
+    } else if (op == 3) {
+      mp[j & 1][1] = __builtin_amdgcn_exp2f(me1);
+      asm volatile("" : "+v"(mp[j & 1][1]));
+    } else if (op == 4) {
+      psum[qb] += mp[j & 1][0];  // the row sum is taken from the fp32 probabilities ...
+      asm volatile("" : "+v"(psum[qb]));
+    } else if (op == 5) {
+      psum[qb] += mp[j & 1][1];
+      asm volatile("" : "+v"(psum[qb]));
+    } else {
+      uint32_t w = pack2<T>(mp[j & 1][0], mp[j & 1][1]);  // ... P itself is rounded to the model dtype (reference :398-400)
+      asm volatile("" : "+v"(w));
+      pw[qb][s2][jp] = w;
+    }
+  };
+  // row max of S over a 32-key block in three parts (part 2 ends with the partner-lane exchange)
+  float mxa = 0.f, mxb = 0.f;
+  auto max_part = [&](const f32x16& a, int part, float& out) __attribute__((always_inline)) {
+    if (part == 0) {
+      mxa = max3(a[0], a[1], a[2]), mxb = max3(a[3], a[4], a[5]);
+      mxa = max3(mxa, a[6], a[7]);
+    } else if (part == 1) {
+      mxb = max3(mxb, a[8], a[9]);
+      mxa = max3(mxa, a[10], a[11]), mxb = max3(mxb, a[12], a[13]);
+    } else {
+      const float mx = max3(mxa, mxb, fmaxf(a[14], a[15]));
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      out = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+  };
+  // running-max bookkeeping of the NEXT unit for one query block (its logits' row max is in mx_raw).
+  // Deferred rescale (MI355X guide T13): the running max follows the row max only once it has grown by more than
+  // P4_THR in the exp2 domain, so probabilities reach at most 2^P4_THR instead of 1 - bf16 / fp16 keep their relative
+  // precision there and the fp32 sums have the headroom - and the 128-register rescale of O becomes rare (with an
+  // exact running max some row of a wave grows in every 5th unit of random data).  Every quantity at the old scale
+  // (O, l; no P is pending at the decision) is scaled exactly once.  P4_THR = 0 is the textbook rule.  The running
+  // max starts at a large negative FINITE value: no -inf special case on the common path (3 VALU per query block and
+  // unit), a row's first visible key always takes, and exp2(-inf c + 1e30) of a masked logit is still 0.
+  auto chain = [&](int qb) __attribute__((always_inline)) {
+    mx_new[qb] = mx_raw[qb] * scale_log2e;
+    take[qb] = mx_new[qb] - m_run[qb] > (float)P4_THR;
+  };
+  // mask of unit (t, kb), rare: key kk of the unit is visible to this lane's query iff kk < lim.  Branch-free integer
+  // form (sign mask): a compare per logit would put dozens of lane masks into SGPR pairs at once.
+  auto unit_needs_mask = [&](int t, int kb) __attribute__((always_inline)) {
+    const bool cached = t < ntc;
+    const int j0 = (cached ? t * PF_KT : (t - ntc) * PF_KT) + 32 * kb;
+    const int count = (cached ? Lc : la_vis) - j0;
+    return count < 32 || (!cached && j0 + 31 > m0);  // workgroup-uniform
+  };
+  auto unit_mask = [&](int t, int kb, f32x16(&sc_)[2]) __attribute__((always_inline)) {
+    const bool cached = t < ntc;
+    const int j0 = (cached ? t * PF_KT : (t - ntc) * PF_KT) + 32 * kb;
+    const int count = (cached ? Lc : la_vis) - j0;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int lim = (cached ? count : min(count, tok[qb] - j0 + 1)) - 4 * h;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = (i & 3) + 8 * (i >> 2);
+        const uint32_t vis = (uint32_t)((kk - lim) >> 31);  // ~0 = visible
+        sc_[qb][i] = __uint_as_float((__float_as_uint(sc_[qb][i]) & vis) | (0xff800000u & ~vis));
+      }
+    }
+  };
+  auto rescale_if_grew = [&]() __attribute__((always_inline)) {
+    if (__any(take[0] || take[1])) {  // rare: some row of the wave moves its running max
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float alpha = take[qb] ? __builtin_amdgcn_exp2f(m_run[qb] - mx_new[qb]) : 1.f;
+        m_run[qb] = take[qb] ? mx_new[qb] : m_run[qb];
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[qb][db][i] *= alpha;
+      }
+    }
+  };
+
+  // phase A of a unit: S(next) = K[next unit] Q^T beside the first ITEMS_A exp items of the current unit.
+  // Entry: kfr[0..2] hold k-steps 0-2 of the next unit's K block.  Exit: vfr[0..2] hold this unit's first V fragments.
+  auto phase_a = [&](const lds_char* kbp, const lds_char* vbp, const f32x16(&sc_)[2], f32x16(&sn_)[2], auto extra)
+                     __attribute__((always_inline)) {
+    static_for<0, 16>([&](auto kk_c) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value;
+      constexpr int s = kk >> 1, qb = kk & 1;
+      if (qb == 0 && s + 3 < KS) kfr[(s + 3) % 4] = k_read(kbp, s + 3);
+      if (s == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], z);
+      } else {
+        sn_[qb] = mfma32<T>(kfr[s % 4], qf[qb][s], sn_[qb]);
+      }
+      static_for<p4_mb(kk), p4_mb(kk + 1)>([&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
+      if (kk == 11) vfr[0] = v_read(vbp, 0);
+      if (kk == 13) vfr[1] = v_read(vbp, 1);
+      if (kk == 15) vfr[2] = v_read(vbp, 2);
+      extra(kk);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // phase B of a unit: O^T += V[unit]^T P^T beside the remaining exp items (first half), then the row max and the
+  // running-max bookkeeping of the next unit (second half).  (tn, kbn) = the next unit, whose logits are in sn_.
+  // Exit: kfr[0..2] hold k-steps 0-2 of the K block at kbp_next (the unit after the next).
+  auto phase_b = [&](const lds_char* vbp, const lds_char* kbp_next, const f32x16(&sc_)[2], f32x16(&sn_)[2], int tn,
+                     int kbn, auto extra) __attribute__((always_inline)) {
+    static_for<0, 8>([&](auto kk_c) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value;
+      constexpr int i = kk >> 1, qb = kk & 1;
+      if (qb == 0) vfr[(i + 3) % 4] = v_read(vbp, i + 3);
+      oacc[qb][i & 3] = mfma32<T>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][0]), oacc[qb][i & 3]);
+      static_for<p4_mb(16 + kk), p4_mb(16 + kk + 1)>(
+          [&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
+      if (kk == 7) {
+        l_run[0] += psum[0];
+        l_run[1] += psum[1];
+        psum[0] = psum[1] = 0.f;
+      }
+      extra(kk);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (unit_needs_mask(tn, kbn)) unit_mask(tn, kbn, sn_);
+#pragma unroll
+    for (int kk = 8; kk < 16; ++kk) {
+      const int i = kk >> 1, qb = kk & 1;
+      if (qb == 0 && i + 3 < 8) vfr[(i + 3) % 4] = v_read(vbp, i + 3);
+      oacc[qb][i & 3] = mfma32<T>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][1]), oacc[qb][i & 3]);
+      if (kk < 14) max_part(sn_[(kk - 8) / 3], (kk - 8) % 3, mx_raw[(kk - 8) / 3]);
+      if (kk == 11) kfr[0] = k_read(kbp_next, 0);
+      if (kk == 13) kfr[1] = k_read(kbp_next, 1);
+      if (kk == 14) chain(0);
+      if (kk == 15) {
+        chain(1);
+        kfr[2] = k_read(kbp_next, 2);
+      }
+      extra(kk);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    rescale_if_grew();
+  };
+  auto no_extra = [](int) {};
+
+  // ---- prologue: tiles 0 and 1 staged, tiles 2 and 3 in flight; S(0, keys 0-31) and its bookkeeping unpipelined ----
+  // A tile's loads are issued two iterations before its LDS writes (two register sets): every workgroup of a
+  // kv-head walks the same K/V stream at the same pace, so each fetch is a miss somewhere and all of them wait for it.
+  tile_desc(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload_piece(0, i);
+  tile_desc(1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload_piece(1, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lstore_piece(0, 0, i);
+  tile_desc(2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload_piece(0, i);
+  lds_barrier();
+  f32x16 sX[2], sY[2];
+  {
+    const lds_char* kbp = k_ptr(0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sX[0][i] = 0.f, sX[1][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const s16x8 a0 = k_read(kbp, s);
+      sX[0] = mfma32<T>(a0, qf[0][s], sX[0]);
+      sX[1] = mfma32<T>(a0, qf[1][s], sX[1]);
+    }
+    if (unit_needs_mask(0, 0)) unit_mask(0, 0, sX);
+#pragma unroll
+    for (int part = 0; part < 6; ++part) max_part(sX[part / 3], part % 3, mx_raw[part / 3]);
+    chain(0);
+    chain(1);
+    rescale_if_grew();  // O and l are still zero: this only moves the running max
+    const lds_char* kb1 = k_ptr(0, 1);
+    kfr[0] = k_read(kb1, 0);
+    kfr[1] = k_read(kb1, 1);
+    kfr[2] = k_read(kb1, 2);
+  }
+  // tile 1 (set 1) to LDS; its set then receives tile 3
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lstore_piece(1, 1, i);
+  tile_desc(3);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload_piece(1, i);
+  lds_barrier();
+
+  // one tile = two units.  SET (compile-time) = t & 1: the register set that holds tile t+2 on entry and receives
+  // tile t+4; cur = t % 3 = the LDS buffer of tile t.
+  auto tile_body = [&](int t, int cur, auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    const int nxt = cur == 2 ? 0 : cur + 1;   // (t + 1) % 3
+    const int nxt2 = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
+    // unit (t, keys 0-31): logits in sX; the next unit is (t, keys 32-63), then (t + 1, keys 0-31)
+    {
+      const lds_char* vbp = v_ptr(cur, 0);
+      phase_a(k_ptr(cur, 1), vbp, sX, sY, no_extra);
+      phase_b(vbp, k_ptr(nxt, 0), sX, sY, t, 1, no_extra);
+    }
+    // unit (t, keys 32-63): logits in sY.  On the last tile S(t + 1) is computed from a stale K tile and never used.
+    // Its shadows also carry the staging: tile t+2 goes from its register set to LDS during phase A, the loads of
+    // tile t+4 into the same set are issued during phase B.
+    {
+      const lds_char* vbp = v_ptr(cur, 1);
+      phase_a(k_ptr(nxt, 0), vbp, sY, sX, [&](int kk) __attribute__((always_inline)) {
+        if (kk & 1) lstore_piece(SET, nxt2, kk >> 1);
+      });
+      phase_b(vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, [&](int kk) __attribute__((always_inline)) {
+        if (kk == 0) tile_desc(t + 4);
+        if (kk & 1) gload_piece(SET, kk >> 1);
+      });
+    }
+    lds_barrier();
+  };
+  // Pairs of tiles, then an odd last one: with the second body under an `if` inside the loop, hipcc's wait-count
+  // pass merges "set 0 loaded last" into the loop header and drains vmcnt to 0 in front of every LDS write of set 0.
+  int cur = 0;  // t % 3
+  int t = 0;
+  for (; t + 1 < ntiles; t += 2) {
+    tile_body(t, cur, std::integral_constant<int, 0>{});
+    cur = cur == 2 ? 0 : cur + 1;
+    tile_body(t + 1, cur, std::integral_constant<int, 1>{});
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  if (t < ntiles) tile_body(t, cur, std::integral_constant<int, 0>{});
+
+  // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ---------------------------
+  char* ob = smem + wave * (64 * PF_OSTRIDE);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int d = db * 32 + 8 * i4 + 4 * h;
+        const uint32_t w0 = pack2<T>(oacc[qb][db][4 * i4] * inv, oacc[qb][db][4 * i4 + 1] * inv);
+        const uint32_t w1 = pack2<T>(oacc[qb][db][4 * i4 + 2] * inv, oacc[qb][db][4 * i4 + 3] * inv);
+        *reinterpret_cast<uint2*>(ob + (qb * 32 + r) * PF_OSTRIDE + d * 2) = make_uint2(w0, w1);
+      }
+    }
+  }
+  // the wave re-reads only what it wrote itself: LDS ops of one wave execute in order, no barrier needed
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int rr = it * 4 + lane / 16;
+    const int ch = lane % 16;
+    const int grow = wave * 64 + rr;
+    const int ghead = g * G + grow / BM;
+    const int gtok = m0 + grow % BM;
+    if (gtok < La) {
+      const uint4 val = *reinterpret_cast<const uint4*>(ob + rr * PF_OSTRIDE + ch * 16);
+      *reinterpret_cast<uint4*>(out + ((size_t)(s0 + gtok) * HQ + ghead) * D + ch * 8) = val;
+    }
+  }
+}
+
+// CVLLM_PREFILL=8wave selects the 8-wave kernel for every shape (A/B measurements and the cross-check test)
+static bool prefill_force_8wave() {
+  const char* e = getenv("CVLLM_PREFILL");
+  return e && e[0] == '8';
+}
+
 template <typename T, int D, int G>
 static int launch_prefill(const void* q, const void* k, const void* v, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                           int64_t sv_n, int64_t sv_h, const void* kc, const void* vc, void* out, const int* seq_lens,
@@ -382,12 +917,21 @@ static int launch_prefill(const void* q, const void* k, const void* v, int64_t s
                           int PS, int NLP, float scale, hipStream_t st) {
   constexpr int BM = PF_ROWS / G;
   const int nqt = (max_seqlen_q + BM - 1) / BM;
-  auto kern = prefill_attn_kernel<T, D, G>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PF_SMEM);
-    attr_done = true;
+  if constexpr (D == 128) {
+    // 4-wave structure unless a 64-key tile would straddle pages (page size not a multiple of 64), the caller's row
+    // strides do not fit its 32-bit buffer offsets, or CVLLM_PREFILL=8wave
+    if (!prefill_force_8wave() && PS % PF_KT == 0 && sk_n * 2 * 64 < 0x7fffffffLL && sv_n * 2 * 64 < 0x7fffffffLL) {
+      auto kern4 = prefill_attn_w4_kernel<T, G>;
+      set_dyn_lds_once(kern4, P4_SMEM);
+      hipLaunchKernelGGL(kern4, dim3(nqt * B * HKV), dim3(P4_THREADS), P4_SMEM, st, (const uint16_t*)q,
+                         (const uint16_t*)k, (const uint16_t*)v, sq_n, sk_n, sk_h, sv_n, sv_h, (const uint16_t*)kc,
+                         (const uint16_t*)vc, (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP,
+                         scale * 1.4426950408889634f);
+      return check_launch();
+    }
   }
+  auto kern = prefill_attn_kernel<T, D, G>;
+  set_dyn_lds_once(kern, PF_SMEM);
   hipLaunchKernelGGL(kern, dim3(nqt * B * HKV), dim3(PF_THREADS), PF_SMEM, st, (const uint16_t*)q, (const uint16_t*)k,
                      (const uint16_t*)v, sq_n, sk_n, sk_h, sv_n, sv_h, (const uint16_t*)kc, (const uint16_t*)vc,
                      (uint16_t*)out, seq_lens, page_table, bmap, cu, B, HKV, PS, NLP, scale * 1.4426950408889634f);

@@ -184,3 +184,99 @@ def test_prefill_chunked_equals_one_shot(dev, split):
                               torch.tensor([0, N], dtype=torch.int32), HKV, PS, 1.0 / math.sqrt(D)).float()
     assert torch.allclose(two.cpu().float(), ref, rtol=1e-6, atol=tol(dtype)), (two.cpu().float() - ref).abs().max()
     assert torch.allclose(one.cpu().float(), ref, rtol=1e-6, atol=tol(dtype))
+
+
+def _both_structures(fn):
+    """Run fn() with the default dispatch (4-wave kernel where it applies) and with CVLLM_PREFILL=8wave."""
+    import os
+
+    out4 = fn()
+    os.environ["CVLLM_PREFILL"] = "8wave"
+    try:
+        out8 = fn()
+    finally:
+        del os.environ["CVLLM_PREFILL"]
+    torch.cuda.synchronize()
+    return out4, out8
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_prefill_both_structures_and_deferred_rescale(dev, dtype):
+    """The 4-wave kernel defers the rescale of O until a row's max has grown by more than 2^8 (P4_THR) and updates the
+    running max per 32-key unit; the 8-wave kernel rescales on any growth, per 64-key tile.  A bounded random input
+    never takes the rescale branch after the first tiles, so this input is built to take BOTH branches many times
+    (MI355X guide rule 26): logits along one direction that climb in small steps (a few units of 2^x per 32 keys:
+    deferred), jump by far more than the threshold (rescale), fall, and climb again - over a cached prefix and an
+    appended block, for query rows of different scale.  Both kernels must meet the attention tolerance against the
+    fp32 oracle; so must their difference."""
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    B, HQ, HKV, D, PS = 1, 8, 2, 128, 128
+    g = torch.Generator().manual_seed(321)
+    Lc, N = 700, 1500
+    lens = torch.tensor([[Lc, Lc - 37]], dtype=torch.int32)
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=11)
+    u = torch.randn(D, generator=g)
+    u = u / u.norm()
+    scale = 1.0 / math.sqrt(D)
+
+    def staircase(n, start):
+        # target logit (exp2 domain) of key j along u for a query q = qs * u: steps of +2.5 per 32 keys, a +30 jump
+        # every 400 keys, a -40 drop every 700
+        j = torch.arange(n) + start
+        return 2.5 * (j // 32) + 30.0 * (j // 400) - 40.0 * (j // 700)
+
+    qs = 8.0
+    c = scale * 1.4426950408889634
+    def keys(n, start):
+        a = staircase(n, start) / (qs * c)  # so that (qs u) . (a u) * scale * log2e = staircase
+        return a[:, None] * u[None, :] + 0.05 * torch.randn(n, D, generator=g)
+
+    # cached prefix rows of both heads follow the staircase too
+    for h in range(HKV):
+        L = int(lens[0, h])
+        rows = O.cache_rows(pt[int(bm[0]), h], L, PS)
+        kc[rows] = keys(L, 0).to(dtype)
+    k = torch.stack([keys(N, Lc), keys(N, Lc + 13)], dim=1).to(dtype)
+    v = torch.randn(N, HKV, D, generator=g).to(dtype)
+    q = (qs * u)[None, None, :] * (0.5 + torch.rand(N, HQ, 1, generator=g)) + 0.1 * torch.randn(N, HQ, D, generator=g)
+    q = q.to(dtype)
+    cu = torch.tensor([0, N], dtype=torch.int32)
+    args = (kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), cu.to(dev), N, int(lens.max()), HKV, PS, scale)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out4, out8 = _both_structures(lambda: causal_sparse_varlen_with_cache(qd, kd, vd, *args))
+    ref = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale).float()
+    for name, o in (("4-wave", out4), ("8-wave", out8)):
+        o = o.cpu().float()
+        assert torch.isfinite(o).all(), name
+        assert torch.allclose(o, ref, rtol=1e-6, atol=tol(dtype)), (name, (o - ref).abs().max())
+    assert torch.allclose(out4.float(), out8.float(), rtol=1e-6, atol=tol(dtype))
+
+
+def test_prefill_both_structures_random(dev):
+    """Every dispatch condition of the 4-wave kernel (D = 128, page size % 64 == 0) on a ragged batch with per-head
+    prefix lengths: both kernels against the oracle."""
+    from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
+
+    dtype, B, HQ, HKV, D, PS = torch.bfloat16, 3, 32, 8, 128, 128
+    g = torch.Generator().manual_seed(17)
+    lens = torch.randint(0, 400, (B, HKV), generator=g, dtype=torch.int32)
+    lens[1, 3] = 0
+    lens[2, 0] = 64   # a full last cached tile
+    lens[0, 5] = 33   # one key into the second unit of a tile
+    kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, dtype, seed=3)
+    append = [1, 190, 321]
+    cu = torch.tensor([0] + torch.tensor(append).cumsum(0).tolist(), dtype=torch.int32)
+    N = int(cu[-1])
+    q = torch.randn(N, HQ, D, generator=g).to(dtype)
+    k = torch.randn(N, HKV, D, generator=g).to(dtype)
+    v = torch.randn(N, HKV, D, generator=g).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    args = (kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), cu.to(dev), max(append), int(lens.max()),
+            HKV, PS, scale)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out4, out8 = _both_structures(lambda: causal_sparse_varlen_with_cache(qd, kd, vd, *args))
+    ref = O.prefill_attention(q, k, v, kc, vc, lens, pt, bm, cu, HKV, PS, scale).float()
+    for name, o in (("4-wave", out4), ("8-wave", out8)):
+        o = o.cpu().float()
+        assert torch.allclose(o, ref, rtol=1e-6, atol=tol(dtype)), (name, (o - ref).abs().max())
