@@ -625,6 +625,265 @@ __global__ __launch_bounds__(LV_FT) void leverage_fused_kernel(const uint16_t* _
     scores[(size_t)(beg + i) * HKV + hh] = fmaxf(sc, 0.f);
   }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// a5 in one kernel with the sketch held in REGISTERS (default for chunks <= 512 rows).  leverage_fused_kernel above
+// keeps X (512 x 48 fp32 = 98 KB) in LDS, so one workgroup owns a CU, and its Gram and its per-row forward
+// substitution run on the VALU (LDS-read bound / 1152 dependent FMAs per row: ~ 12 + 50 us at 32 K x 8).  Here a
+// wave owns 128 rows of the chunk and keeps their sketch in its MFMA accumulators (4 blocks x 32 registers), the
+// chunk's keys are read once, and every O(rows x 48 x 48) step runs on the matrix pipe in fp32:
+//   1. X = K PHI (MFMA 32x32x16) for the wave's four 32-row blocks, the next block's key rows in flight;
+//      column sums of X from the accumulators -> mu; X - mu in place (rows past the chunk: zero);
+//   2. per block: accumulators -> wave-private LDS tile, Gram of the tile accumulated by fp32 MFMAs
+//      (v_mfma_f32_16x16x4_f32: exact fp32 products, six 16 x 16 blocks of the symmetric 48 x 48 matrix); the waves'
+//      partial Grams are summed in a fixed order;
+//   3. one wave: Cholesky G = L L^T in registers (one v_rsq per column instead of sqrt + division), then W = L^-1
+//      (lane c solves L w = e_c);
+//   4. per block: tile again, Y = X W^T by fp32 MFMAs (the zero blocks of the triangular W skipped),
+//      score_i = || y_i ||^2 = x_i^T G^-1 x_i.
+// A workgroup is 4 waves, 45 KB of LDS and < 256 registers: two share a CU.  Sums are in a fixed order: bit-reproducible.
+constexpr int LV2_T = 256;
+constexpr int LV2_W = LV2_T / 64;     // waves = wave tiles
+constexpr int LV2_NB = LV_FMAX / (32 * LV2_W);  // 32-row blocks per wave (4)
+constexpr int LV2_TILE = 32 * LV_LD;  // floats per wave tile (1568 >= 6 * 256: also holds a wave's partial Gram)
+constexpr size_t LV2_SMEM =
+    (size_t)(LV2_W * LV2_TILE + LV_KD * LV_LD + LV_KD * LV_KD + LV_KD + LV2_W * LV_KMAX + LV_KMAX) * sizeof(float);
+template <typename T, int D>
+__global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_t* __restrict__ key, int64_t s_n,
+                                                                  int64_t s_h, const uint16_t* __restrict__ phi,
+                                                                  float* __restrict__ scores,
+                                                                  const int* __restrict__ chunk_cu, int HKV, int kdim,
+                                                                  float reg) {
+  constexpr int KS = D / 16;
+  static_assert(D <= 128 && LV_KD == 48, "tile / block layout");
+  extern __shared__ __attribute__((aligned(16))) char lv_smem[];
+  float* s_tiles = reinterpret_cast<float*>(lv_smem);   // [LV2_W][32][LV_LD]
+  float* s_G = s_tiles + LV2_W * LV2_TILE;              // [48][LV_LD]  Gram, then W = L^-1
+  float* s_L = s_G + LV_KD * LV_LD;                     // [48][48]     L, strictly lower part (zero elsewhere)
+  float* s_Li = s_L + LV_KD * LV_KD;                    // [48]         1 / L[k][k]
+  float* s_part = s_Li + LV_KD;                         // [LV2_W][64]  per-wave column sums
+  float* s_mu = s_part + LV2_W * LV_KMAX;               // [64]
+  uint16_t(*s_phiT)[D + 8] = reinterpret_cast<uint16_t(*)[D + 8]>(lv_smem);  // aliases the tiles until pf is loaded
+
+  const int cidx = blockIdx.x / HKV, hh = blockIdx.x % HKV;
+  const int beg = chunk_cu[cidx], end = chunk_cu[cidx + 1];
+  const int L = end - beg;
+  if (L <= 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const uint16_t* kh = key + (size_t)beg * s_n + (size_t)hh * s_h;
+  const int w0 = wave * (32 * LV2_NB);  // first row of this wave
+
+  // key fragments of a block (A operand: lane = row r, dims 16 s + 8 h ..); rows past the chunk read as zero
+  uint4 kr[KS];
+  auto load_block = [&](int n0) __attribute__((always_inline)) {
+    const int n = n0 + r;
+    const bool valid = n < L;
+    const uint16_t* kp = kh + (size_t)(valid ? n : 0) * s_n + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kr[s] = valid ? *reinterpret_cast<const uint4*>(kp + 16 * s) : make_uint4(0, 0, 0, 0);
+  };
+  load_block(w0);  // in flight while PHI is staged
+
+  // ---- PHI^T fragments (B operand of the sketch), as in sketch_kernel
+  for (int e = tid; e < LV_KMAX * D; e += LV2_T) {
+    const int col = e / D, d = e % D;
+    s_phiT[col][d] = col < kdim ? phi[(size_t)d * kdim + col] : (uint16_t)0;
+  }
+  __syncthreads();
+  f32x16 x[LV2_NB][2];  // the wave's sketch: x[b][cb][i] = X[row w0 + 32 b + (i&3) + 8 (i>>2) + 4 h][col 32 cb + r]
+  {
+    s16x8 pf[2][KS];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) pf[cb][s] = *reinterpret_cast<const s16x8*>(&s_phiT[cb * 32 + r][16 * s + 8 * h]);
+    // ---- 1. sketch of the wave's blocks
+#pragma unroll
+    for (int b = 0; b < LV2_NB; ++b) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[b][cb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        x[b][0] = mfma32s<T>(__builtin_bit_cast(s16x8, kr[s]), pf[0][s], x[b][0]);
+        x[b][1] = mfma32s<T>(__builtin_bit_cast(s16x8, kr[s]), pf[1][s], x[b][1]);
+      }
+      if (b + 1 < LV2_NB) load_block(w0 + 32 * (b + 1));
+    }
+  }
+  // column means: lane sums its rows, + the partner half, waves combined through LDS in a fixed order
+  {
+    float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int b = 0; b < LV2_NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) c0 += x[b][0][i], c1 += x[b][1][i];
+    c0 += __shfl_xor(c0, 32, 64);
+    c1 += __shfl_xor(c1, 32, 64);
+    if (h == 0) s_part[wave * LV_KMAX + r] = c0, s_part[wave * LV_KMAX + 32 + r] = c1;
+    __syncthreads();  // also: every wave has its PHI fragments, s_phiT may become the tiles
+    if (tid < LV_KMAX) {
+      float t = 0.f;
+      for (int w = 0; w < LV2_W; ++w) t += s_part[w * LV_KMAX + tid];
+      s_mu[tid] = t / (float)L;
+    }
+    __syncthreads();
+    const float mu0 = s_mu[r], mu1 = s_mu[32 + r];
+#pragma unroll
+    for (int b = 0; b < LV2_NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool in = w0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h < L;
+        x[b][0][i] = in ? x[b][0][i] - mu0 : 0.f;
+        x[b][1][i] = in ? x[b][1][i] - mu1 : 0.f;
+      }
+  }
+  float* tile = s_tiles + wave * LV2_TILE;
+  auto put_tile = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+      tile[rr * LV_LD + r] = x[b][0][i];
+      if (r < LV_KD - 32) tile[rr * LV_LD + 32 + r] = x[b][1][i];
+    }
+  };
+  const int kq = lane >> 4, cl = lane & 15;  // fp32 MFMA 16x16x4: k index / row-or-column index of a lane's operand
+
+  // ---- 2. Gram: six 16 x 16 blocks (ja <= jb) per wave, fp32 MFMA over the tile's rows
+  {
+    f32x4 g[6];
+#pragma unroll
+    for (int bI = 0; bI < 6; ++bI) g[bI] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < LV2_NB; ++b) {
+      if (w0 + 32 * b < L) {  // wave-uniform: blocks past the chunk are all zero
+        put_tile(b);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const float* row = tile + (4 * ks + kq) * LV_LD + cl;
+          const float f0 = row[0], f1 = row[16], f2 = row[32];
+          g[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f0, f0, g[0], 0, 0, 0);
+          g[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f0, f1, g[1], 0, 0, 0);
+          g[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(f0, f2, g[2], 0, 0, 0);
+          g[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1, f1, g[3], 0, 0, 0);
+          g[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1, f2, g[4], 0, 0, 0);
+          g[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(f2, f2, g[5], 0, 0, 0);
+        }
+      }
+    }
+    // partial blocks into the wave's own tile: [block][row 16][col 16]; C[row = 4 (lane / 16) + i][col = lane % 16]
+#pragma unroll
+    for (int bI = 0; bI < 6; ++bI)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tile[bI * 256 + (4 * kq + i) * 16 + cl] = g[bI][i];
+    __syncthreads();
+    for (int e = tid; e < LV_KD * LV_KD; e += LV2_T) {
+      const int a = e / LV_KD, b = e % LV_KD;
+      const int lo = a < b ? a : b, hi = a < b ? b : a;  // block (lo / 16, hi / 16) holds G[lo][hi]
+      const int ja = lo >> 4, jb = hi >> 4;
+      const int bI = ja == 0 ? jb : (ja == 1 ? 2 + jb : 5);
+      float t = 0.f;
+      for (int w = 0; w < LV2_W; ++w) t += s_tiles[w * LV2_TILE + bI * 256 + (lo & 15) * 16 + (hi & 15)];
+      s_G[a * LV_LD + b] = t + (a == b ? reg : 0.f);
+    }
+    __syncthreads();
+  }
+  // ---- 3. one wave: Cholesky in registers (lane i owns row i; column j of L is broadcast with v_readlane), W = L^-1
+  if (tid < 64) {
+    const int rown = lane < LV_KD ? lane : LV_KD - 1;
+    {
+      float a[LV_KD];
+      float dinv_mine = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < LV_KD; ++cc) a[cc] = s_G[rown * LV_LD + cc];
+#pragma unroll
+      for (int j = 0; j < LV_KD; ++j) {
+        const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j));
+        const float dinv = __builtin_amdgcn_rsqf(piv);  // 1 / L[j][j]
+        a[j] *= dinv;                                    // lane j: sqrt(piv) = L[j][j]; lanes i > j: L[i][j]
+        dinv_mine = (lane == j) ? dinv : dinv_mine;
+#pragma unroll
+        for (int kk = j + 1; kk < LV_KD; ++kk) {
+          const float lkj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), kk));
+          a[kk] = fmaf(-a[j], lkj, a[kk]);  // A[i][k] -= L[i][j] L[k][j]   (meaningful for i >= k)
+        }
+      }
+      if (lane < LV_KD) {
+#pragma unroll
+        for (int cc = 0; cc < LV_KD; ++cc) s_L[lane * LV_KD + cc] = cc < lane ? a[cc] : 0.f;
+        s_Li[lane] = dinv_mine;
+      }
+    }
+    // W = L^-1, column c by lane c: forward substitution of e_c; L is read as broadcast float4s (same wave wrote it)
+    {
+      float w[LV_KD];
+#pragma unroll
+      for (int kk = 0; kk < LV_KD; ++kk) {
+        float t = (kk == rown) ? 1.f : 0.f;
+#pragma unroll
+        for (int m4 = 0; m4 < (kk + 3) / 4; ++m4) {  // entries m >= kk of row kk are zero: no masking needed
+          const float4 l4 = *reinterpret_cast<const float4*>(s_L + kk * LV_KD + 4 * m4);
+          t = fmaf(-l4.x, w[4 * m4], t);
+          if (4 * m4 + 1 < kk) t = fmaf(-l4.y, w[4 * m4 + 1], t);
+          if (4 * m4 + 2 < kk) t = fmaf(-l4.z, w[4 * m4 + 2], t);
+          if (4 * m4 + 3 < kk) t = fmaf(-l4.w, w[4 * m4 + 3], t);
+        }
+        w[kk] = t * s_Li[kk];
+        // anchor: w is only stored after the loop, so hipcc otherwise sinks the whole FMA chain below the 294 float4
+        // loads of the 48 steps and spills every loaded value
+        asm volatile("" : "+v"(w[kk]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < LV_KD) {
+#pragma unroll
+        for (int kk = 0; kk < LV_KD; ++kk) s_G[kk * LV_LD + lane] = w[kk];  // W[kk][c]; zero above the diagonal
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 4. Y = X W^T by fp32 MFMAs, score_i = sum_j Y[i][j]^2.  B operand: B[k = c][col = j] = W[16 jb + j][c]; the
+  // blocks of W right of the diagonal block are zero: column block jb needs k-steps 0 .. 4 (jb + 1) - 1 only.
+  {
+    float wB[3][12];
+#pragma unroll
+    for (int jb = 0; jb < 3; ++jb)
+#pragma unroll
+      for (int ks = 0; ks < 4 * (jb + 1); ++ks) wB[jb][ks] = s_G[(16 * jb + cl) * LV_LD + 4 * ks + kq];
+#pragma unroll
+    for (int b = 0; b < LV2_NB; ++b) {
+      const int n0 = w0 + 32 * b;
+      if (n0 < L) {  // wave-uniform
+        put_tile(b);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          f32x4 y[3];
+#pragma unroll
+          for (int jb = 0; jb < 3; ++jb) y[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 12; ++ks) {
+            const float a = tile[(16 * nb + cl) * LV_LD + 4 * ks + kq];  // A[row = n][k = c] = Xc[n][c]
+#pragma unroll
+            for (int jb = 0; jb < 3; ++jb)
+              if (ks < 4 * (jb + 1)) y[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wB[jb][ks], y[jb], 0, 0, 0);
+          }
+          // lane (kq, cl) holds Y[n = 16 nb + 4 kq + v][j = 16 jb + cl]: squares summed over jb, then over 16 lanes
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float q = y[0][v] * y[0][v];
+            q = fmaf(y[1][v], y[1][v], q);
+            q = fmaf(y[2][v], y[2][v], q);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+            const int n = n0 + 16 * nb + 4 * kq + v;
+            if (cl == v && n < L) scores[(size_t)(beg + n) * HKV + hh] = fmaxf(q, 0.f);
+          }
+        }
+      }
+    }
+  }
+}
+
 constexpr size_t LV_FUSED_SMEM =
     (size_t)(LV_FMAX * LV_LD + 2 * LV_KD * LV_LD + LV_KD * LV_KD + 2 * LV_KD + 256) * sizeof(float);
 
@@ -952,20 +1211,25 @@ extern "C" int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_
   if ((s_n % 8) || (s_h % 8)) return CVLLM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (max_chunk_rows > 0 && max_chunk_rows <= LV_FMAX) {
-    // every chunk fits the fused kernel's LDS image of the sketch: one launch, no workspace
+    // one launch, no workspace: the recomputing kernel (two workgroups per CU), or with CVLLM_LEVERAGE=resident the
+    // kernel that keeps the chunk's sketch in LDS (A/B measurements and the cross-check test)
+    const char* lv_env = getenv("CVLLM_LEVERAGE");
+    const bool resident = lv_env && lv_env[0] == 'r';
 #define LF(T_, D_)                                                                                                     \
   {                                                                                                                    \
     static_assert((size_t)LV_KMAX * (D_ + 8) * 2 <= (size_t)LV_FMAX * LV_LD * 4, "PHI^T must fit inside the X image"); \
-    auto kern = leverage_fused_kernel<T_, D_>;                                                                         \
-    static bool attr[64] = {false};                                                                                    \
-    int dev = 0;                                                                                                       \
-    (void)hipGetDevice(&dev);                                                                                          \
-    if (dev < 0 || dev >= 64 || !attr[dev]) {                                                                          \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LV_FUSED_SMEM);    \
-      if (dev >= 0 && dev < 64) attr[dev] = true;                                                                      \
+    static_assert((size_t)LV_KMAX * (D_ + 8) * 2 <= (size_t)LV2_W * LV2_TILE * 4, "PHI^T must fit inside the tiles");      \
+    if (resident) {                                                                                                    \
+      auto kern = leverage_fused_kernel<T_, D_>;                                                                       \
+      set_dyn_lds_once(kern, (int)LV_FUSED_SMEM);                                                                      \
+      hipLaunchKernelGGL(kern, dim3(n_chunks* HKV), dim3(LV_FT), LV_FUSED_SMEM, st, (const uint16_t*)key_states, s_n,   \
+                         s_h, (const uint16_t*)phi, scores, chunk_cu, HKV, sketch_dim, regularizer);                   \
+    } else {                                                                                                           \
+      auto kern = leverage_fused2_kernel<T_, D_>;                                                                      \
+      set_dyn_lds_once(kern, (int)LV2_SMEM);                                                                           \
+      hipLaunchKernelGGL(kern, dim3(n_chunks* HKV), dim3(LV2_T), LV2_SMEM, st, (const uint16_t*)key_states, s_n, s_h,   \
+                         (const uint16_t*)phi, scores, chunk_cu, HKV, sketch_dim, regularizer);                        \
     }                                                                                                                  \
-    hipLaunchKernelGGL(kern, dim3(n_chunks* HKV), dim3(LV_FT), LV_FUSED_SMEM, st, (const uint16_t*)key_states, s_n, s_h, \
-                       (const uint16_t*)phi, scores, chunk_cu, HKV, sketch_dim, regularizer);                          \
   }
     if (dtype == CVLLM_F16 && D == 128) LF(F16, 128)
     else if (dtype == CVLLM_F16 && D == 64) LF(F16, 64)
