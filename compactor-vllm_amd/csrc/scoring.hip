@@ -1064,43 +1064,46 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
 }
 
 // lse[b, g, row] = log2-domain log-sum-exp of window row `row` over all scored keys, from the per-tile (max, sum)
-// partials of pass 1.  One workgroup per (b, g); thread = (row, slice of the tiles); slices meet in LDS.
-constexpr int SK_LSE_SLICES = 16;
-constexpr int SK_LSE_ROWS = 64;  // window rows per workgroup
-__global__ __launch_bounds__(SK_LSE_ROWS * SK_LSE_SLICES) void snapkv_lse_kernel(
-    const float* __restrict__ part, float* __restrict__ lse, const int* __restrict__ cu_k, int HKV, int w, int G,
-    int ntile_max) {
+// partials of pass 1.  One WAVE per (b, g, row): lane l folds tiles l, l + 64, ... (independent loads, fixed order),
+// then the 64 lane states are merged by a fixed shuffle tree - reproducible.  (The first version gave a row to one
+// thread per 16-tile slice, 32 workgroups in all: 24 us of mostly exposed load latency at 256 tiles.)
+constexpr int SK_LSE_T = 256;  // 4 rows per workgroup
+__global__ __launch_bounds__(SK_LSE_T) void snapkv_lse_kernel(const float* __restrict__ part, float* __restrict__ lse,
+                                                              const int* __restrict__ cu_k, int HKV, int w, int G,
+                                                              int ntile_max) {
   constexpr int ROWS = SK_MAXQB * 32;
-  __shared__ float s_m[SK_LSE_SLICES][SK_LSE_ROWS], s_s[SK_LSE_SLICES][SK_LSE_ROWS];
-  const int bg = blockIdx.x / (ROWS / SK_LSE_ROWS), b = bg / HKV;
-  const int rl = threadIdx.x % SK_LSE_ROWS, sl = threadIdx.x / SK_LSE_ROWS;
-  const int row = (blockIdx.x % (ROWS / SK_LSE_ROWS)) * SK_LSE_ROWS + rl;
+  const int lane = threadIdx.x & 63;
+  const int gr = blockIdx.x * (SK_LSE_T / 64) + (threadIdx.x >> 6);  // global row index: (b * HKV + g) * ROWS + row
+  const int bg = gr / ROWS, row = gr % ROWS, b = bg / HKV;
   const int keff = cu_k[b + 1] - cu_k[b] - w;
   const int ntile = keff > 0 ? (keff + SK_TILE - 1) / SK_TILE : 0;
-  const int rows_b = w * G;
+  if (row >= w * G) return;  // wave-uniform
+  const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)bg * ntile_max * ROWS + row;
   float m = -INFINITY, ssum = 0.f;
-  if (row < rows_b) {
-    const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)bg * ntile_max * ROWS + row;
-#pragma unroll 4
-    for (int t = sl; t < ntile; t += SK_LSE_SLICES) {  // a slice folds its tiles in tile order (fixed: reproducible)
-      const float2 ms = pp[(size_t)t * ROWS];
-      const float mn = fmaxf(m, ms.x);
-      ssum = ssum * __builtin_amdgcn_exp2f(m - mn) + ms.y * __builtin_amdgcn_exp2f(ms.x - mn);
+  for (int t0 = lane; t0 < ntile; t0 += 4 * 64) {
+    float2 ms[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      ms[u] = t0 + 64 * u < ntile ? pp[(size_t)(t0 + 64 * u) * ROWS] : make_float2(-INFINITY, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float mn = fmaxf(m, ms[u].x);
+      const float mn_safe = mn == -INFINITY ? 0.f : mn;
+      ssum = ssum * __builtin_amdgcn_exp2f(m - mn_safe) + ms[u].y * __builtin_amdgcn_exp2f(ms[u].x - mn_safe);
       m = mn;
     }
   }
-  s_m[sl][rl] = m;
-  s_s[sl][rl] = ssum;
-  __syncthreads();
-  if (sl == 0 && row < rows_b) {
-    float M = s_m[0][rl];
 #pragma unroll
-    for (int i = 1; i < SK_LSE_SLICES; ++i) M = fmaxf(M, s_m[i][rl]);
-    float tot = 0.f;
-#pragma unroll
-    for (int i = 0; i < SK_LSE_SLICES; ++i) tot += s_s[i][rl] * __builtin_amdgcn_exp2f(s_m[i][rl] - M);
-    lse[(size_t)bg * ROWS + row] = M + __builtin_amdgcn_logf(tot);
+  for (int o = 32; o > 0; o >>= 1) {
+    const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(ssum, o, 64);
+    const float mn = fmaxf(m, mo);
+    const float mn_safe = mn == -INFINITY ? 0.f : mn;
+    // the partner computes the same two products in the other order; float addition commutes: identical in both lanes
+    const float a = ssum * __builtin_amdgcn_exp2f(m - mn_safe), c2 = so * __builtin_amdgcn_exp2f(mo - mn_safe);
+    ssum = (lane & o) ? c2 + a : a + c2;
+    m = mn;
   }
+  if (lane == 0) lse[(size_t)bg * ROWS + row] = m + __builtin_amdgcn_logf(ssum);
 }
 
 }  // namespace cvllm
@@ -1279,7 +1282,7 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
   {                                                                                                                   \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,  \
                        sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \
-    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32 / SK_LSE_ROWS)), dim3(SK_LSE_ROWS* SK_LSE_SLICES), 0, st,                   \
+    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32) / (SK_LSE_T / 64)), dim3(SK_LSE_T), 0, st,                \
                        (const float*)part, lse, cu_k, HKV, w, G_, ntile);                                             \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
                        sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \

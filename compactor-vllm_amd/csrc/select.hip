@@ -28,6 +28,14 @@ __device__ __forceinline__ uint32_t order_key(float x) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending uint order == ascending float order
 }
 
+// agent-scope load of a word other workgroups updated with atomics in this launch (bypasses the non-coherent caches)
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int SEL_E = 4;  // elements per thread per iteration: 4 independent loads in flight (the loops are
                           // L2-latency bound with one), thread t owns the CONSECUTIVE indices base + 4t .. +3
 
@@ -301,11 +309,20 @@ struct SjState {
   int pad_;
 };
 
+template <int NT>
+__device__ void radix_scan_step(uint32_t* __restrict__ g, SjState* __restrict__ stp, int r0, int pass,
+                                uint32_t* s_state, int* s_wsum);
+__device__ __forceinline__ bool last_arriver(int* counter, int participants, int* s_ticket);
+
 __global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
-                                                       const int* __restrict__ bmap, const SjState* __restrict__ st,
-                                                       uint32_t* __restrict__ gh, int H, int pass, int NS,
+                                                       const int* __restrict__ bmap, SjState* __restrict__ st,
+                                                       uint32_t* __restrict__ gh, const int* __restrict__ retain,
+                                                       int* __restrict__ tickets, int H, int pass, int NS,
                                                        int reserved) {
   __shared__ uint32_t hist[SEL_BINS];
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SJ_T / 64];
+  __shared__ int s_ticket;
   const int b = blockIdx.x / NS, sl = blockIdx.x % NS;
   const int tid = threadIdx.x;
   const int n0 = cu[b];
@@ -345,13 +362,23 @@ __global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__
     const uint32_t c = hist[i];
     if (c) atomicAdd(&g[i], c);
   }
+  // the radix step on the finished histogram, by the last slice workgroup of the sequence to arrive (this used to be
+  // a launch of its own: the selection is launch-latency bound, 18 launches of ~ 4.7 us at 32 K x 8)
+  const int participants = (n + SJ_SLICE - 1) / SJ_SLICE;
+  if (last_arriver(tickets + b, participants, &s_ticket)) {
+    int rr = retain[b];
+    rr = rr < 0 ? 0 : (rr > n ? n : rr);
+    radix_scan_step<SJ_T>(g, st + b, rr, pass, s_state, s_wsum);
+  }
 }
 
 // one radix step on a finished global histogram g[4096]: fixes the next digit of the r-th largest key, updates the
 // state and zeroes the histogram for the next pass.  r0 = the rank to select (used in pass 0), r0 == 0 keeps nothing.
 // All SEL_T threads of the workgroup must call.
+template <int NT>
 __device__ void radix_scan_step(uint32_t* __restrict__ g, SjState* __restrict__ stp, int r0, int pass,
                                 uint32_t* s_state, int* s_wsum) {
+  constexpr int BP = SEL_BINS / NT;  // bins per thread
   const int tid = threadIdx.x;
   SjState s = *stp;
   int remaining;
@@ -361,7 +388,7 @@ __device__ void radix_scan_step(uint32_t* __restrict__ g, SjState* __restrict__ 
     remaining = r0;
     if (r0 == 0) {  // keep nothing: a threshold above every key, quota 0
       if (tid == 0) *stp = SjState{0xffffffffu, 0, 32, 0};
-      for (int i = tid; i < SEL_BINS; i += SEL_T) g[i] = 0;
+      for (int i = tid; i < SEL_BINS; i += NT) g[i] = 0;
       return;
     }
   } else {
@@ -370,53 +397,86 @@ __device__ void radix_scan_step(uint32_t* __restrict__ g, SjState* __restrict__ 
   }
   const int bits = pass < 2 ? 12 : 8;
   const int nb = 1 << bits;
-  const int b0 = nb - 1 - 4 * tid;  // thread t owns bins top-4t .. top-4t-3
-  uint32_t c[4] = {0, 0, 0, 0};
-  if (b0 >= 3) {
-    c[0] = g[b0]; c[1] = g[b0 - 1]; c[2] = g[b0 - 2]; c[3] = g[b0 - 3];
+  const int b0 = nb - 1 - BP * tid;  // thread t owns bins top - BP t .. top - BP t - (BP - 1)
+  uint32_t c[BP];
+  int mine = 0;
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    c[j] = b0 - j >= 0 ? ld_agent(&g[b0 - j]) : 0u;
+    mine += (int)c[j];
   }
-  const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
   int tot;
-  const int excl = block_excl_scan_cnt(mine, s_wsum, tot);
+  const int excl = block_excl_scan_cnt_t<NT>(mine, s_wsum, tot);
   if (excl < remaining && remaining <= excl + mine) {
     int acc = excl, d = b0;
-    if (acc + (int)c[0] >= remaining) { d = b0; }
-    else { acc += c[0]; if (acc + (int)c[1] >= remaining) { d = b0 - 1; }
-    else { acc += c[1]; if (acc + (int)c[2] >= remaining) { d = b0 - 2; }
-    else { acc += c[2]; d = b0 - 3; } } }
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      if (!found) {
+        if (acc + (int)c[j] >= remaining) {
+          d = b0 - j;
+          found = true;
+        } else {
+          acc += (int)c[j];
+        }
+      }
+    }
     s_state[0] = (uint32_t)d;
     s_state[1] = (uint32_t)(remaining - acc);
   }
   __syncthreads();
   if (tid == 0) *stp = SjState{(s.prefix << bits) | s_state[0], (int)s_state[1], s.fixed_bits + bits, 0};
-  for (int i = tid; i < SEL_BINS; i += SEL_T) g[i] = 0;  // ready for the next pass (everyone has read its bins)
+  for (int i = tid; i < SEL_BINS; i += NT) g[i] = 0;  // ready for the next pass (everyone has read its bins)
 }
 
-__global__ __launch_bounds__(SEL_T) void sj_scan_kernel(const int* __restrict__ cu, const int* __restrict__ bmap,
-                                                        const int* __restrict__ retain, SjState* __restrict__ st,
-                                                        uint32_t* __restrict__ gh, int H, int pass, int reserved) {
-  __shared__ uint32_t s_state[2];
-  __shared__ int s_wsum[SEL_W];
-  const int b = blockIdx.x;
-  const int Lb = cu[b + 1] - cu[b];
-  if (Lb <= 0 || bmap[b] == reserved) return;
-  const int n = Lb * H;
-  int r = retain[b];
-  r = r < 0 ? 0 : (r > n ? n : r);
-  radix_scan_step(gh + (size_t)b * SEL_BINS, st + b, r, pass, s_state, s_wsum);
+// Last-arriver hand-off inside a launch: every participating workgroup calls this after its global atomics; exactly
+// one of them - the last to arrive - gets `true`.  Everything handed over was written with agent-scope ATOMICS (they
+// are performed at the level all XCDs share) and is read back with agent-scope loads (ld_agent): no cache write-back
+// or invalidate is needed - a __threadfence() pair here (L2 write-back + invalidate per workgroup) made the fused
+// selection slower than the 18 launches it replaced.  The ticket is taken after the workgroup's atomics have been
+// acknowledged.  The counter returns to zero for the next launch.  All threads must call.
+__device__ __forceinline__ bool last_arriver(int* counter, int participants, int* s_ticket) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's atomics are performed (CDNA4 vmcnt counts them)
+  __syncthreads();
+  if (threadIdx.x == 0) *s_ticket = atomicAdd(counter, 1);
+  __syncthreads();
+  const bool last = *s_ticket == participants - 1;
+  if (last && threadIdx.x == 0) atomicExch(counter, 0);
+  return last;
 }
+
+
 
 // per-head counts of keys above / equal to the threshold over one slice
+// Forward declaration of the tail that the last slice workgroup runs (defined below)
+template <int NT>
+__device__ void sj_final_body(int b, const float* __restrict__ scores, const int* __restrict__ cu,
+                              const int* __restrict__ bh_lens0, const SjState* __restrict__ st,
+                              const int* __restrict__ cnt_gt, const int* __restrict__ cnt_eq, int* __restrict__ target,
+                              int* __restrict__ new_lens, int H, int PS, int pad, int* s_wsum, int* s_cnt,
+                              int* s_tot_eq_p);
+
 __global__ __launch_bounds__(SJ_T) void sj_count_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
                                                         const int* __restrict__ bmap, const SjState* __restrict__ st,
-                                                        int* __restrict__ cnt_gt, int* __restrict__ cnt_eq, int H,
-                                                        int NS, int reserved) {
+                                                        int* __restrict__ cnt_gt, int* __restrict__ cnt_eq,
+                                                        const int* __restrict__ bh_lens0, int* __restrict__ target,
+                                                        int* __restrict__ new_lens, int* __restrict__ tickets, int H,
+                                                        int NS, int PS, int pad, int reserved) {
   __shared__ int s_gt[SEL_MAXH], s_eq[SEL_MAXH];
+  __shared__ int s_wsum[SJ_T / 64];
+  __shared__ int s_tot_eq;
+  __shared__ int s_ticket;
   const int b = blockIdx.x / NS, sl = blockIdx.x % NS;
   const int tid = threadIdx.x;
   const int n0 = cu[b];
   const int Lb = cu[b + 1] - n0;
-  if (Lb <= 0 || bmap[b] == reserved) return;
+  if (Lb <= 0 || bmap[b] == reserved) {  // nothing to select: the first slice writes the trivial result
+    if (sl == 0 && tid < H) {
+      target[b * H + tid] = 0;
+      new_lens[b * H + tid] = bh_lens0[b * H + tid];
+    }
+    return;
+  }
   const int n = Lb * H;
   const int beg = sl * SJ_SLICE;
   if (beg >= n) return;
@@ -460,45 +520,41 @@ __global__ __launch_bounds__(SJ_T) void sj_count_kernel(const float* __restrict_
     if (s_gt[tid]) atomicAdd(&cnt_gt[b * SEL_MAXH + tid], s_gt[tid]);
     if (s_eq[tid]) atomicAdd(&cnt_eq[b * SEL_MAXH + tid], s_eq[tid]);
   }
+  // counts -> t_h by the last slice workgroup of the sequence to arrive (was a launch of its own)
+  if (last_arriver(tickets + b, (n + SJ_SLICE - 1) / SJ_SLICE, &s_ticket))
+    sj_final_body<SJ_T>(b, scores, cu, bh_lens0, st, cnt_gt, cnt_eq, target, new_lens, H, PS, pad, s_wsum, s_gt,
+                        &s_tot_eq);
 }
 
-__global__ __launch_bounds__(SEL_T) void sj_final_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
-                                                         const int* __restrict__ bh_lens0, const int* __restrict__ bmap,
-                                                         const SjState* __restrict__ st, const int* __restrict__ cnt_gt,
-                                                         const int* __restrict__ cnt_eq, int* __restrict__ target,
-                                                         int* __restrict__ new_lens, int H, int PS, int pad,
-                                                         int reserved) {
-  __shared__ int s_wsum[SEL_W];
-  __shared__ int s_cnt[SEL_MAXH];
-  __shared__ int s_tot_eq;
-  const int b = blockIdx.x, tid = threadIdx.x;
+// per-head counts of sequence b -> t_h (target) and the new lengths; all NT threads of one workgroup call
+template <int NT>
+__device__ void sj_final_body(int b, const float* __restrict__ scores, const int* __restrict__ cu,
+                              const int* __restrict__ bh_lens0, const SjState* __restrict__ st,
+                              const int* __restrict__ cnt_gt, const int* __restrict__ cnt_eq, int* __restrict__ target,
+                              int* __restrict__ new_lens, int H, int PS, int pad, int* s_wsum, int* s_cnt,
+                              int* s_tot_eq_p) {
+  const int tid = threadIdx.x;
   const int n0 = cu[b];
   const int Lb = cu[b + 1] - n0;
-  if (Lb <= 0 || bmap[b] == reserved) {
-    if (tid < H) {
-      target[b * H + tid] = 0;
-      new_lens[b * H + tid] = bh_lens0[b * H + tid];
-    }
-    return;
-  }
+  int& s_tot_eq = *s_tot_eq_p;
   const int n = Lb * H;
   const uint32_t v = st[b].prefix;
   const int quota = st[b].remaining;
   if (tid == 0) {
     int t = 0;
-    for (int hh = 0; hh < H; ++hh) t += cnt_eq[b * SEL_MAXH + hh];
+    for (int hh = 0; hh < H; ++hh) t += ld_agent(&cnt_eq[b * SEL_MAXH + hh]);
     s_tot_eq = t;
   }
-  if (tid < H) s_cnt[tid] = cnt_gt[b * SEL_MAXH + tid];
+  if (tid < H) s_cnt[tid] = ld_agent(&cnt_gt[b * SEL_MAXH + tid]);
   __syncthreads();
   const int tot_eq = s_tot_eq;
   if (quota >= tot_eq) {
-    if (tid < H) s_cnt[tid] += cnt_eq[b * SEL_MAXH + tid];
+    if (tid < H) s_cnt[tid] += ld_agent(&cnt_eq[b * SEL_MAXH + tid]);
   } else if (quota > 0) {
     // partial ties: the first `quota` elements equal to v in ascending flat index are kept
     const float* base = scores + (size_t)n0 * H;
     int ties_before = 0;
-    for (int i0 = 0; i0 < n && ties_before < quota; i0 += SEL_T * SEL_E) {
+    for (int i0 = 0; i0 < n && ties_before < quota; i0 += NT * SEL_E) {
       bool tie[SEL_E];
       int ntie = 0;
 #pragma unroll
@@ -508,7 +564,7 @@ __global__ __launch_bounds__(SEL_T) void sj_final_kernel(const float* __restrict
         ntie += tie[e] ? 1 : 0;
       }
       int tot;
-      int tr = ties_before + block_excl_scan_cnt(ntie, s_wsum, tot);
+      int tr = ties_before + block_excl_scan_cnt_t<NT>(ntie, s_wsum, tot);
 #pragma unroll
       for (int e = 0; e < SEL_E; ++e) {
         if (tie[e] && tr < quota) atomicAdd(&s_cnt[(i0 + tid * SEL_E + e) % H], 1);
@@ -547,9 +603,13 @@ __device__ __forceinline__ int sh_rank(const int* __restrict__ target, int bh, i
 }
 
 __global__ __launch_bounds__(SJ_T) void sh_hist_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
-                                                       const int* __restrict__ target, const SjState* __restrict__ st,
-                                                       uint32_t* __restrict__ gh, int H, int pass, int P) {
+                                                       const int* __restrict__ target, SjState* __restrict__ st,
+                                                       uint32_t* __restrict__ gh, int* __restrict__ tickets, int H,
+                                                       int pass, int P) {
   __shared__ uint32_t hist[SEL_BINS];
+  __shared__ uint32_t s_state[2];
+  __shared__ int s_wsum[SJ_T / 64];
+  __shared__ int s_ticket;
   const int p = blockIdx.x % P, bh = blockIdx.x / P;
   const int b = bh / H, h = bh % H;
   const int tid = threadIdx.x;
@@ -578,20 +638,11 @@ __global__ __launch_bounds__(SJ_T) void sh_hist_kernel(const float* __restrict__
     const uint32_t c = hist[i];
     if (c) atomicAdd(&g[i], c);
   }
+  // radix step by the last slice workgroup of the column to arrive (see sj_hist_kernel)
+  if (last_arriver(tickets + bh, (Lb + SH_SLICE - 1) / SH_SLICE, &s_ticket))
+    radix_scan_step<SJ_T>(g, st + bh, t, pass, s_state, s_wsum);
 }
 
-__global__ __launch_bounds__(SEL_T) void sh_scan_kernel(const int* __restrict__ cu, const int* __restrict__ target,
-                                                        SjState* __restrict__ st, uint32_t* __restrict__ gh, int H,
-                                                        int pass) {
-  __shared__ uint32_t s_state[2];
-  __shared__ int s_wsum[SEL_W];
-  const int bh = blockIdx.x, b = bh / H;
-  const int Lb = cu[b + 1] - cu[b];
-  if (Lb <= 0) return;
-  const int t = sh_rank(target, bh, Lb);
-  if (t <= 0 || t >= Lb) return;
-  radix_scan_step(gh + (size_t)bh * SEL_BINS, st + bh, t, pass, s_state, s_wsum);
-}
 
 // slice_cnt[(bh * P + p) * 2 + {0, 1}] = #keys above / equal to the column's threshold in slice p
 __global__ __launch_bounds__(SJ_T) void sh_count_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
@@ -691,14 +742,23 @@ __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict_
 
 using namespace cvllm;
 
+// workspace: target[B, H] | joint path: global histograms, states, per-head counts, tickets | per-head path: per-column
+// histograms, states, tickets, per-slice counts.  Everything up to the per-slice counts is zeroed by ONE memset.
+static size_t sel_target_bytes(int B, int H) { return ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16; }
+static size_t sel_joint_bytes(int B) {
+  return (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t) + 4 * sizeof(int32_t));
+}
+static size_t sel_head_zero_bytes(int B, int H) {
+  return (size_t)B * H * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 4 * sizeof(int32_t));
+}
+
 extern "C" size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen) {
   if (B <= 0 || H <= 0) return 0;
-  size_t bytes = ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;  // target[B,H]
-  if ((long)max_seqlen * H >= SJ_MIN)  // multi-workgroup joint path: global histogram, state, per-head counts
-    bytes += (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
-  if (max_seqlen >= SH_MIN) {  // multi-workgroup per-head path: per-column histogram + state, per-slice counts
+  size_t bytes = sel_target_bytes(B, H);
+  if ((long)max_seqlen * H >= SJ_MIN) bytes += sel_joint_bytes(B);
+  if (max_seqlen >= SH_MIN) {
     const size_t P = ((size_t)max_seqlen + SH_SLICE - 1) / SH_SLICE;
-    bytes += (size_t)B * H * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + P * 2 * sizeof(int32_t));
+    bytes += sel_head_zero_bytes(B, H) + (size_t)B * H * P * 2 * sizeof(int32_t);
   }
   return bytes;
 }
@@ -715,44 +775,43 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
   if (!workspace || workspace_bytes < cvllm_select_workspace_bytes(B, H, max_seqlen)) return CVLLM_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int* target = (int*)workspace;
-  if ((long)max_seqlen * H >= SJ_MIN) {
-    char* p = (char*)workspace + ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;
-    const size_t extra = (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
-    uint32_t* gh = (uint32_t*)p;
+  const bool joint_multi = (long)max_seqlen * H >= SJ_MIN;
+  const int P = (max_seqlen + SH_SLICE - 1) / SH_SLICE;
+  const bool head_multi = max_seqlen >= SH_MIN && P <= SH_MAXP;
+  char* pj = (char*)workspace + sel_target_bytes(B, H);
+  char* ph = pj + (joint_multi ? sel_joint_bytes(B) : 0);
+  {
+    // one memset for both multi-workgroup paths (their regions are adjacent)
+    const size_t zero = (joint_multi ? sel_joint_bytes(B) : 0) + (head_multi ? sel_head_zero_bytes(B, H) : 0);
+    char* z0 = joint_multi ? pj : ph;
+    if (zero && hipMemsetAsync(z0, 0, zero, st) != hipSuccess) return CVLLM_ERR_LAUNCH;
+  }
+  if (joint_multi) {
+    uint32_t* gh = (uint32_t*)pj;
     SjState* sst = (SjState*)(gh + (size_t)B * SEL_BINS);
     int* cnt_gt = (int*)(sst + B);
     int* cnt_eq = cnt_gt + (size_t)B * SEL_MAXH;
-    if (hipMemsetAsync(p, 0, extra, st) != hipSuccess) return CVLLM_ERR_LAUNCH;
+    int* tickets = cnt_eq + (size_t)B * SEL_MAXH;
     const int NS = (int)(((long)max_seqlen * H + SJ_SLICE - 1) / SJ_SLICE);
-    for (int pass = 0; pass < 3; ++pass) {
-      hipLaunchKernelGGL(sj_hist_kernel, dim3(B * NS), dim3(SJ_T), 0, st, scores, cu_seqlens_k, batch_mapping, sst, gh, H,
-                         pass, NS, reserved_batch);
-      hipLaunchKernelGGL(sj_scan_kernel, dim3(B), dim3(SEL_T), 0, st, cu_seqlens_k, batch_mapping, retain, sst, gh, H,
-                         pass, reserved_batch);
-    }
+    // 3 radix passes (histogram + the radix step by the last workgroup to arrive), then counts + t_h likewise
+    for (int pass = 0; pass < 3; ++pass)
+      hipLaunchKernelGGL(sj_hist_kernel, dim3(B * NS), dim3(SJ_T), 0, st, scores, cu_seqlens_k, batch_mapping, sst, gh,
+                         retain, tickets, H, pass, NS, reserved_batch);
     hipLaunchKernelGGL(sj_count_kernel, dim3(B * NS), dim3(SJ_T), 0, st, scores, cu_seqlens_k, batch_mapping, sst,
-                       cnt_gt, cnt_eq, H, NS, reserved_batch);
-    hipLaunchKernelGGL(sj_final_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, bh_lens0, batch_mapping, sst,
-                       cnt_gt, cnt_eq, target, new_lens, H, page_size, pad_to_page, reserved_batch);
+                       cnt_gt, cnt_eq, bh_lens0, target, new_lens, tickets, H, NS, page_size, pad_to_page,
+                       reserved_batch);
   } else {
     hipLaunchKernelGGL(select_joint_kernel, dim3(B), dim3(SEL_T), 0, st, scores, cu_seqlens_k, retain, bh_lens0,
                        batch_mapping, target, new_lens, H, page_size, pad_to_page, reserved_batch);
   }
-  const int P = (max_seqlen + SH_SLICE - 1) / SH_SLICE;
-  if (max_seqlen >= SH_MIN && P <= SH_MAXP) {
-    char* p = (char*)workspace + ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16;
-    if ((long)max_seqlen * H >= SJ_MIN)
-      p += (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t));
-    uint32_t* gh2 = (uint32_t*)p;
+  if (head_multi) {
+    uint32_t* gh2 = (uint32_t*)ph;
     SjState* st2 = (SjState*)(gh2 + (size_t)B * H * SEL_BINS);
-    int* slice_cnt = (int*)(st2 + (size_t)B * H);
-    if (hipMemsetAsync(p, 0, (size_t)B * H * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState)), st) != hipSuccess)
-      return CVLLM_ERR_LAUNCH;
-    for (int pass = 0; pass < 3; ++pass) {
-      hipLaunchKernelGGL(sh_hist_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, gh2, H,
-                         pass, P);
-      hipLaunchKernelGGL(sh_scan_kernel, dim3(B * H), dim3(SEL_T), 0, st, cu_seqlens_k, target, st2, gh2, H, pass);
-    }
+    int* tickets2 = (int*)(st2 + (size_t)B * H);
+    int* slice_cnt = (int*)(ph + sel_head_zero_bytes(B, H));
+    for (int pass = 0; pass < 3; ++pass)
+      hipLaunchKernelGGL(sh_hist_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, gh2,
+                         tickets2, H, pass, P);
     hipLaunchKernelGGL(sh_count_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, slice_cnt,
                        H, P);
     hipLaunchKernelGGL(sh_write_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, slice_cnt,
