@@ -190,7 +190,11 @@ def roofline_prefill_attn(model, ctx, rounds=3):
     sec = e0.elapsed_time(e1) * 1e-3 / rounds
     flops = 4.0 * ctx * ctx * cfg.head_dim * cfg.heads / 2
     tf = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "prefill_attn_kernel", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
+    import os
+    kern = ("prefill_attn_w4_kernel (4 waves, one per SIMD)"
+            if cfg.head_dim == 128 and a.page_size % 64 == 0 and not os.environ.get("CVLLM_PREFILL", "").startswith("8")
+            else "prefill_attn_kernel (8 waves)")
+    return {"bound": "mfma", "kernel": kern, "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops_per_launch": flops}
 

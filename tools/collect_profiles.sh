@@ -32,7 +32,7 @@ echo "[2/7] decode PMC done"
 # 3. SQ counters of the prefill kernel (two passes of 8 counters)
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/s1" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq1.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$O/s2" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq2.log" 2>&1
-{ echo "prefill_attn_kernel<BF16,128,4>, 1 x 32768 tokens, per launch (SQ counters are in 4-cycle units summed over waves / SIMDs)"; python3 tools/pmc_sq.py "$O/s1" prefill_attn; python3 tools/pmc_sq.py "$O/s2" prefill_attn; } > "$O/${R}_prefill_sq_counters.txt"
+{ echo "prefill attention (prefill_attn_w4_kernel<BF16,4>), 1 x 32768 tokens, per launch (SQ counters are in 4-cycle units summed over waves / SIMDs)"; python3 tools/pmc_sq.py "$O/s1" prefill_attn; python3 tools/pmc_sq.py "$O/s2" prefill_attn; } > "$O/${R}_prefill_sq_counters.txt"
 rm -rf "$O/s1" "$O/s2"
 echo "[3/7] prefill SQ counters done"
 # 4. per-workgroup phase stamps of the decode kernel on one clock (debug build; back-to-back launches)
@@ -40,6 +40,7 @@ timeout -k 10 200 python3 tools/decode_rt.py > "$O/${R}_decode_phase_stamps.txt"
 echo "[4/7] decode stamps done"
 # 5. stand-alone kernel timings; decode with the in-launch merge and with the two-kernel merge on the same box
 { python3 tools/microbench.py prefill --L 16384; python3 tools/microbench.py prefill --L 32768;
+  echo "# same, CVLLM_PREFILL=8wave (the 8-wave kernel of round 1):"; CVLLM_PREFILL=8wave python3 tools/microbench.py prefill --L 32768;
   echo "# decode attention, C3 per-layer shape, in-launch split merge (default):"; python3 tools/microbench.py decode --L 16640 --splits 32;
   echo "# same, CVLLM_DECODE_MERGE=two-kernel (stage 1 + decode_stage2_kernel):"; CVLLM_DECODE_MERGE=two-kernel python3 tools/microbench.py decode --L 16640 --splits 32;
   python3 tools/microbench.py decode --L 65536 --B 8 --splits 4; python3 tools/microbench.py scoring --L 32768; } > "$O/${R}_microbench.txt" 2>&1
@@ -47,6 +48,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm" -- py
 CVLLM_DECODE_MERGE=two-kernel timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm2" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/ktm2.log" 2>&1
 { echo "# rocprofv3 --kernel-trace of tools/microbench.py decode --L 16640 --splits 32 (9 caches back to back in a HIP graph)"; echo "# in-launch merge:"; python3 tools/prof_summary.py "$O/ktm" decode; echo "# CVLLM_DECODE_MERGE=two-kernel:"; python3 tools/prof_summary.py "$O/ktm2" decode; } > "$O/${R}_decode_kernel_durations.txt"
 rm -rf "$O/ktm" "$O/ktm2"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/kts" -- python3 tools/microbench.py scoring --L 32768 > "$O/kts.log" 2>&1
+{ echo "# rocprofv3 --kernel-trace of tools/microbench.py scoring --L 32768 (every store-stream kernel at the C3 layer shape, alone on the GPU)"; python3 tools/prof_summary.py "$O/kts"; } > "$O/${R}_scoring_kernel_durations.txt"
+rm -rf "$O/kts"
 echo "[5/7] microbench done"
 # 6. the bench lines: default run (C3, with cpu_baseline), C2, C4
 python3 bench.py > "$O/bench_c3.log" 2>&1
