@@ -83,16 +83,27 @@ def test_leverage_unnormalised_fp32_accuracy(dev):
     L = _lib.lib()
     nb = L.cvllm_leverage_workspace_bytes(N, H, 48)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    import os
+
     both = []
-    for longest in (max(chunks), 0):  # <= 512: the one-kernel path (sketch kept in LDS); 0: sketch through the workspace
+    # <= 512 rows per chunk: ONE kernel, sketch in registers + fp32 MFMA Gram / solve (default) or sketch resident in LDS
+    # (CVLLM_LEVERAGE=resident); 0: sketch kernel + solve kernel through the workspace
+    for longest, env in ((max(chunks), None), (max(chunks), "resident"), (0, None)):
         scores.fill_(float("nan"))
-        st = L.cvllm_leverage_scores(kd.data_ptr(), kd.stride(0), kd.stride(1), pd.data_ptr(), scores.data_ptr(),
-                                     cu.data_ptr(), len(chunks), N, H, D, 48, 5e-3, 1, longest, ws.data_ptr(), nb,
-                                     torch.cuda.current_stream().cuda_stream)
+        if env:
+            os.environ["CVLLM_LEVERAGE"] = env
+        try:
+            st = L.cvllm_leverage_scores(kd.data_ptr(), kd.stride(0), kd.stride(1), pd.data_ptr(), scores.data_ptr(),
+                                         cu.data_ptr(), len(chunks), N, H, D, 48, 5e-3, 1, longest, ws.data_ptr(), nb,
+                                         torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("CVLLM_LEVERAGE", None)
         assert st == 0
         both.append(scores.cpu().clone())
-    # same arithmetic except the order of the Gram row sums (two halves in the one-kernel path)
-    assert torch.allclose(both[0], both[1], rtol=1e-4, atol=1e-6), (both[0] - both[1]).abs().max()
+    # the same fp32 arithmetic in three summation orders (and W = L^-1 applied instead of a forward substitution)
+    assert torch.allclose(both[0], both[2], rtol=1e-4, atol=1e-6), (both[0] - both[2]).abs().max()
+    assert torch.allclose(both[1], both[2], rtol=1e-4, atol=1e-6), (both[1] - both[2]).abs().max()
     ref = O.leverage_scores(k, lens, PHI, normalize=False, chunk_size=512, out_dtype=torch.float32)
     assert torch.allclose(scores.cpu(), ref, rtol=1e-3, atol=2e-4), (scores.cpu() - ref).abs().max()
 
