@@ -119,9 +119,12 @@ __global__ void fill_inf_kernel(void* __restrict__ x, const int* __restrict__ ra
 //   Same fragments for both passes, only the operand order swaps.
 // =====================================================================================================
 constexpr int CM_CHUNK = 128;
+#ifndef CM_OCC
+#define CM_OCC 2
+#endif
 template <typename T, int D, int G>
 // min 2 waves per SIMD: left alone hipcc spends 272 registers (1 wave per SIMD = ONE workgroup per CU; measured 180 us)
-__global__ __launch_bounds__(256, 2) void chunk_mass_kernel(const uint16_t* __restrict__ q,
+__global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t* __restrict__ q,
                                                          const uint16_t* __restrict__ k, int64_t sq_n, int64_t sk_n,
                                                          int64_t sk_h, float* __restrict__ mass,
                                                          const int* __restrict__ cu, int B, int HKV, int nchunk_max,
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void chunk_mass_kernel(const uint16_t* __re
   constexpr int QB = G;  // 32-row query blocks per wave: rows = 128*G over 4 waves
   __shared__ __attribute__((aligned(16))) char s_k[CM_CHUNK * 256];
   __shared__ float s_mass[4][CM_CHUNK];
+  __shared__ __attribute__((aligned(16))) float s_lse[4][32];
 
   const int bid = blockIdx.x;
   const int g = bid % HKV;
@@ -153,51 +157,73 @@ __global__ __launch_bounds__(256, 2) void chunk_mass_kernel(const uint16_t* __re
   __syncthreads();
 
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};  // key = kb*32 + r, this lane's half of the query rows
-#pragma unroll 1
-  for (int qb = 0; qb < QB; ++qb) {
-    const int row = (wave * QB + qb) * 32 + r;  // row in [0, 128*G): head = row / 128, token = row % 128
+  // Q fragments of a 32-row query block (row in [0, 128*G): head = row / 128, token = row % 128); the NEXT block's are in
+  // flight while a block is processed (the loads are 32-byte pieces of rows 8 KB apart: latency, not bandwidth)
+  uint4 qn[KS];
+  auto load_q = [&](int qb) __attribute__((always_inline)) {
+    const int row = (wave * QB + qb) * 32 + r;
     const int head = row / CM_CHUNK, tok = row % CM_CHUNK;
     const bool valid_q = tok < M;
-    s16x8 qf[KS];
-    {
-      const uint16_t* qp = q + (size_t)(s0 + t0 + (valid_q ? tok : 0)) * sq_n + (size_t)(g * G + head) * D + 8 * h;
+    const uint16_t* qp = q + (size_t)(s0 + t0 + (valid_q ? tok : 0)) * sq_n + (size_t)(g * G + head) * D + 8 * h;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
-        qf[s] = __builtin_bit_cast(s16x8, t);
-      }
-    }
-    // pass 1: queries on lanes
-    float mx = -INFINITY;
-    f32x16 acc[4];
+    for (int s = 0; s < KS; ++s) qn[s] = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+  };
+  load_q(0);
+#pragma unroll 1
+  for (int qb = 0; qb < QB; ++qb) {
+    const int row = (wave * QB + qb) * 32 + r;
+    const int tok = row % CM_CHUNK;
+    const bool valid_q = tok < M;
+    s16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = __builtin_bit_cast(s16x8, qn[s]);
+    if (qb + 1 < QB) load_q(qb + 1);
+    // pass 1: queries on lanes; row max / row sum folded over the four 32-key blocks (online: one block of logits
+    // live at a time - holding all four cost 48 registers and, with the Q prefetch, spills)
+    float mx = -INFINITY, sum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
+      f32x16 acc;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-        acc[kb] = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[s], acc[kb]);
+        acc = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[s], acc);
       }
+      if (M < CM_CHUNK) {  // workgroup-uniform: only a sequence's last chunk has keys to mask
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const float val = kk < M ? acc[kb][i] * scale_log2e : -INFINITY;
-        acc[kb][i] = val;
-        mx = fmaxf(mx, val);
+        for (int i = 0; i < 16; ++i) {
+          const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          acc[i] = kk < M ? acc[i] : -INFINITY;
+        }
       }
+      // max over the RAW logits (scale > 0 commutes with max), then exp2(s c - m c): one FMA per logit
+      float bm = fmaxf(acc[0], acc[1]);
+#pragma unroll
+      for (int i = 2; i < 16; ++i) bm = fmaxf(bm, acc[i]);
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64)) * scale_log2e;  // key 0 of the chunk is always valid: finite from block 0 on
+      const float mn = fmaxf(mx, bm);
+      float bs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bs += __builtin_amdgcn_exp2f(fmaf(acc[i], scale_log2e, -mn));
+      sum = sum * __builtin_amdgcn_exp2f(mx - mn) + bs;
+      mx = mn;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(acc[kb][i] - mx);
     sum += __shfl_xor(sum, 32, 64);
     // lse in the exp2 domain; invalid query rows get +inf so that they contribute p = 0 in pass 2
     const float lse2 = valid_q ? mx + __builtin_amdgcn_logf(sum) : INFINITY;  // v_log_f32 = log2
+    // the block's 32 row values through LDS (wave-private): pass 2 needs the lse of query rows 8 j + 4 h + 0..3, four
+    // consecutive floats per accumulator quad - 4 ds_read_b128 per block instead of 64 ds_bpermute
+    if (h == 0) s_lse[wave][r] = lse2;
+    float4 l4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l4[j] = *reinterpret_cast<const float4*>(&s_lse[wave][8 * j + 4 * h]);
 
-    // pass 2: keys on lanes, query rows in the accumulator registers
+    // pass 2: keys on lanes, query rows in the accumulator registers.  The K fragments are read from LDS AGAIN (offset
+    // laundered): hipcc otherwise keeps all 32 fragments of pass 1 alive for pass 2 - 128 registers
+    uint32_t koff = 0;
+    asm volatile("" : "+v"(koff));
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       f32x16 a2;
@@ -205,15 +231,14 @@ __global__ __launch_bounds__(256, 2) void chunk_mass_kernel(const uint16_t* __re
       for (int i = 0; i < 16; ++i) a2[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+        const uint4 a = *reinterpret_cast<const uint4*>(s_k + koff + ktile_off(kb * 32 + r, 2 * s + h));
         a2 = mfma32s<T>(qf[s], __builtin_bit_cast(s16x8, a), a2);
       }
       float cs = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int qrow = (i & 3) + 8 * (i >> 2) + 4 * h;  // query row of this register
-        const float l2 = __shfl(lse2, qrow, 64);           // lanes qrow and qrow+32 hold the same value
-        cs += __builtin_amdgcn_exp2f(a2[i] * scale_log2e - l2);
+      for (int i = 0; i < 16; ++i) {  // register i holds query row (i & 3) + 8 (i >> 2) + 4 h
+        const float l2 = (i & 3) == 0 ? l4[i >> 2].x : (i & 3) == 1 ? l4[i >> 2].y : (i & 3) == 2 ? l4[i >> 2].z : l4[i >> 2].w;
+        cs += __builtin_amdgcn_exp2f(fmaf(a2[i], scale_log2e, -l2));
       }
       colsum[kb] += cs;
     }
