@@ -395,7 +395,7 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
 //     their LDS writes, three LDS buffers each for K and V;
 //   * same LDS images and fragment addressing as the 8-wave kernel; the softmax differs in two documented ways: the
 //     running max is updated per 32-key unit (not per 64-key tile) and follows the row max only after it has grown
-//     by more than P4_THR (deferred rescale).  Both kernels meet the attention tolerance against the oracle
+//     by more than P4_THR (deferred rescale).  Both kernels meet the attention tolerance of the parity tests
 //     (tests/test_gpu_prefill.py runs every case on both).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
