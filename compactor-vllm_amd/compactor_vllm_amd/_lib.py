@@ -41,6 +41,8 @@ SIGNATURES = {
     "cvllm_leverage_scores": (_I, [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _Z, _P]),
     "cvllm_snapkv_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "cvllm_snapkv_scores": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _Z, _P]),
+    "cvllm_snapkv_scores_wb": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _Z, _P]),
+    "cvllm_zscore_windowed": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "cvllm_select_workspace_bytes": (_Z, [_I, _I, _I]),
     "cvllm_select_topk": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "cvllm_compact_store": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,

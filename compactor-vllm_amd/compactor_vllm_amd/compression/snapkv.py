@@ -62,7 +62,7 @@ def query_aware_key_scores(
     k: torch.Tensor,  # [N_k, Hk, D]
     cu_seqlens_q: torch.Tensor,  # [B+1], int32
     cu_seqlens_k: torch.Tensor,  # [B+1], int32
-    w: int,
+    w: "torch.Tensor | int",  # [B] int32 or one window for every sequence
     sm_scale: float = None,  # defaults to 1/sqrt(D)
     *,
     accum_scores: torch.Tensor = None,
@@ -72,12 +72,19 @@ def query_aware_key_scores(
 ) -> Optional[torch.Tensor]:
     """s_j = sum over the last `w` queries x G heads of softmax_row(q k^T / sqrt D) restricted to keys
     [0, L-w); trailing 5-tap mean clipped at 128-key tiles (reference BLOCK_K pinned to 128, SURVEY P3);
-    last w keys <- +inf.  fp32 [N_k, Hk].  Only an int window is supported (the engine passes w=32).
-    `max_seqlen_k` avoids a host sync; when omitted it is read from cu_seqlens_k (one sync, like the
-    reference's `w.max().item()`).  Sequences with L <= w come back all +inf (reference: uninitialised)."""
+    last w keys <- +inf.  fp32 [N_k, Hk].  `w` is an int (the engine passes 32) or a [B] int32 tensor of per-sequence
+    windows (one host sync for its maximum, like the reference's `w.max().item()`).  normalize=True z-scores every
+    sequence's scored rows [0, L-w) over all heads (biased variance, eps 1e-12 inside the square root; reference
+    :279-329).  `max_seqlen_k` avoids a host sync; when omitted it is read from cu_seqlens_k.  Sequences with L <= w
+    come back all +inf (reference: uninitialised)."""
     assert q.stride(-1) == 1 and k.stride(-1) == 1, "last dim must be contiguous"
-    assert isinstance(w, int), "per-sequence window tensors are not supported"
     _lib.require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
+    w_b = None
+    if not isinstance(w, int):
+        _lib.require_cuda(w)
+        w_b = _lib.i32(w)
+        assert w_b.numel() == cu_seqlens_q.numel() - 1
+        w = int(w_b.max().item())
     N_q, Hq, D = q.shape
     N_k, Hk, Dk = k.shape
     assert (Hq % Hk) == 0, "Hq must be a multiple of Hk"
@@ -95,14 +102,18 @@ def query_aware_key_scores(
     L = _lib.lib()
     ws_bytes = L.cvllm_snapkv_workspace_bytes(B, Hk, w, int(max_seqlen_k))
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=q.device)
-    st = L.cvllm_snapkv_scores(
+    st = L.cvllm_snapkv_scores_wb(
         q.data_ptr(), k.data_ptr(), q.stride(0), k.stride(0), k.stride(1), out.data_ptr(), cq.data_ptr(), ck.data_ptr(),
-        B, Hq, Hk, D, int(w), float(sm_scale), 5, int(max_seqlen_k), _lib.dtype_code(q.dtype), ws.data_ptr(), ws_bytes,
-        _lib.stream(),
+        _lib.ptr(w_b), B, Hq, Hk, D, int(w), float(sm_scale), 5, int(max_seqlen_k), _lib.dtype_code(q.dtype),
+        ws.data_ptr(), ws_bytes, _lib.stream(),
     )
-    _lib.check(st, "cvllm_snapkv_scores")
+    _lib.check(st, "cvllm_snapkv_scores_wb")
     if normalize:
-        raise NotImplementedError("windowed z-score (snapkv.py:279-329) is dead code upstream (normalize=False)")
+        zb = L.cvllm_zscore_workspace_bytes(B)
+        zws = torch.empty(max(zb, 4), dtype=torch.uint8, device=q.device)
+        st = L.cvllm_zscore_windowed(out.data_ptr(), 2, ck.data_ptr(), _lib.ptr(w_b), int(w), B, Hk, 1e-12, N_k,
+                                     zws.data_ptr(), zb, _lib.stream())
+        _lib.check(st, "cvllm_zscore_windowed")
     if accum_scores is not None:
         if accum_blending is not None:
             accum_scores.mul_(accum_blending)

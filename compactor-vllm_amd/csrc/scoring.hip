@@ -46,10 +46,12 @@ constexpr int ZS_MAXTILES = 32;
 // partials of its segment IN TILE ORDER (deterministic: no float atomics), then normalises its own slice.
 template <int DT>
 __global__ __launch_bounds__(ZS_T) void zscore_partial_kernel(const void* __restrict__ x, const int* __restrict__ cu,
-                                                              int H, int T, float* __restrict__ part) {
+                                                              int H, int T, float* __restrict__ part,
+                                                              const int* __restrict__ trim_b, int trim) {
   __shared__ float s_a[ZS_T / 64], s_b[ZS_T / 64];
   const int seg = blockIdx.x, tile = blockIdx.y;
-  const size_t beg = (size_t)cu[seg] * H, end = (size_t)cu[seg + 1] * H;
+  const int tr = trim_b ? trim_b[seg] : trim;  // rows left out at the end of the segment (windowed form)
+  const size_t beg = (size_t)cu[seg] * H, end = (size_t)max(cu[seg + 1] - tr, 0) * H;
   const size_t n = end > beg ? end - beg : 0;
   const size_t per = (n + T - 1) / T;
   const size_t lo = beg + per * tile, hi = min(lo + per, end);
@@ -83,9 +85,11 @@ __global__ __launch_bounds__(ZS_T) void zscore_partial_kernel(const void* __rest
 template <int DT, int ADT>
 __global__ __launch_bounds__(ZS_T) void zscore_apply_kernel(void* __restrict__ x, const int* __restrict__ cu, int H,
                                                             int T, const float* __restrict__ part,
-                                                            const void* __restrict__ accum, float blend) {
+                                                            const void* __restrict__ accum, float blend,
+                                                            const int* __restrict__ trim_b, int trim, float eps) {
   const int seg = blockIdx.x, tile = blockIdx.y;
-  const size_t beg = (size_t)cu[seg] * H, end = (size_t)cu[seg + 1] * H;
+  const int tr = trim_b ? trim_b[seg] : trim;
+  const size_t beg = (size_t)cu[seg] * H, end = (size_t)max(cu[seg + 1] - tr, 0) * H;
   if (end <= beg) return;
   float sum = 0.f, sq = 0.f;
   for (int t = 0; t < T; ++t) {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(ZS_T) void zscore_apply_kernel(void* __restrict__ x
   const float cnt = (float)(end - beg);
   const float mean = sum / cnt;
   const float var = fmaxf(sq / cnt - mean * mean, 0.f);  // biased, clamped, NO epsilon (compactor.py:258-260)
-  const float invstd = 1.0f / sqrtf(var);
+  const float invstd = 1.0f / sqrtf(var + eps);  // eps = 0 for the Compactor form (compactor.py:258-260)
   const size_t per = (end - beg + T - 1) / T;
   const size_t lo = beg + per * tile, hi = min(lo + per, end);
   for (size_t i = lo + threadIdx.x; i < hi; i += ZS_T) {
@@ -928,7 +932,8 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
                                                      float* __restrict__ scores, float* __restrict__ part,
                                                      const float* __restrict__ lse,
                                                      const int* __restrict__ cu_q, const int* __restrict__ cu_k,
-                                                     int B, int HKV, int w, int ntile_max, float scale_log2e,
+                                                     int B, int HKV, int w_max, const int* __restrict__ w_b,
+                                                     int ntile_max, float scale_log2e,
                                                      int pool) {
   constexpr int KS = D / 16;
   constexpr int CH = D / 8;
@@ -944,9 +949,15 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
   const int b = bid / (HKV * ngrp_max);
   const int kb0 = cu_k[b], Lk = cu_k[b + 1] - kb0;
   const int qend = cu_q[b + 1];
+  const int w = min(w_b ? w_b[b] : w_max, w_max);  // this sequence's window (snapkv.py:351-357: int or [B] tensor)
   const int keff = Lk - w;  // keys that are scored
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
+  if (w <= 0) {  // no window rows: every key's score is an empty sum (what the reference's loops leave: 0)
+    if (PASS2 && grp == 0)
+      for (int i = tid; i < Lk; i += 256) scores[(size_t)(kb0 + i) * HKV + g] = 0.f;
+    return;
+  }
   if (keff <= 0) {  // L <= w: every key is "recent" -> +inf (the reference leaves these rows uninitialised)
     if (PASS2 && grp == 0)
       for (int i = tid; i < Lk; i += 256) scores[(size_t)(kb0 + i) * HKV + g] = INFINITY;
@@ -1094,12 +1105,13 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
 // thread per 16-tile slice, 32 workgroups in all: 24 us of mostly exposed load latency at 256 tiles.)
 constexpr int SK_LSE_T = 256;  // 4 rows per workgroup
 __global__ __launch_bounds__(SK_LSE_T) void snapkv_lse_kernel(const float* __restrict__ part, float* __restrict__ lse,
-                                                              const int* __restrict__ cu_k, int HKV, int w, int G,
-                                                              int ntile_max) {
+                                                              const int* __restrict__ cu_k, int HKV, int w_max,
+                                                              const int* __restrict__ w_b, int G, int ntile_max) {
   constexpr int ROWS = SK_MAXQB * 32;
   const int lane = threadIdx.x & 63;
   const int gr = blockIdx.x * (SK_LSE_T / 64) + (threadIdx.x >> 6);  // global row index: (b * HKV + g) * ROWS + row
   const int bg = gr / ROWS, row = gr % ROWS, b = bg / HKV;
+  const int w = min(w_b ? w_b[b] : w_max, w_max);
   const int keff = cu_k[b + 1] - cu_k[b] - w;
   const int ntile = keff > 0 ? (keff + SK_TILE - 1) / SK_TILE : 0;
   if (row >= w * G) return;  // wave-uniform
@@ -1140,10 +1152,10 @@ extern "C" size_t cvllm_zscore_workspace_bytes(int n_segments) {
   return n_segments > 0 ? (size_t)n_segments * ZS_MAXTILES * 2 * sizeof(float) : 0;
 }
 
-extern "C" int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
-                                     const void* accum, int accum_dtype, float blend, const int32_t* prot_ranges,
-                                     int n_ranges, int total_rows, void* workspace, size_t workspace_bytes,
-                                     cvllm_stream_t stream) {
+static int zscore_impl(void* x, int score_dtype, const int32_t* cu, int n_segments, int H, const void* accum,
+                       int accum_dtype, float blend, const int32_t* prot_ranges, int n_ranges, int total_rows,
+                       void* workspace, size_t workspace_bytes, const int32_t* trim_b, int trim, float eps,
+                       cvllm_stream_t stream) {
   if (!x || (n_segments > 0 && !cu) || H <= 0 || n_segments < 0 || n_ranges < 0) return CVLLM_ERR_ARG;
   if (score_dtype < 0 || score_dtype > 2 || (accum && (accum_dtype < 0 || accum_dtype > 2))) return CVLLM_ERR_SHAPE;
   if (n_ranges > 0 && !prot_ranges) return CVLLM_ERR_ARG;
@@ -1157,11 +1169,12 @@ extern "C" int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu
     T = T < 1 ? 1 : (T > ZS_MAXTILES ? ZS_MAXTILES : T);
     float* part = (float*)workspace;
     dim3 grid(n_segments, T);
-    if (score_dtype == 0) hipLaunchKernelGGL((zscore_partial_kernel<0>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part);
-    else if (score_dtype == 1) hipLaunchKernelGGL((zscore_partial_kernel<1>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part);
-    else hipLaunchKernelGGL((zscore_partial_kernel<2>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part);
-#define ZS(DT, ADT) \
-  hipLaunchKernelGGL((zscore_apply_kernel<DT, ADT>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part, accum, blend)
+    if (score_dtype == 0) hipLaunchKernelGGL((zscore_partial_kernel<0>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part, trim_b, trim);
+    else if (score_dtype == 1) hipLaunchKernelGGL((zscore_partial_kernel<1>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part, trim_b, trim);
+    else hipLaunchKernelGGL((zscore_partial_kernel<2>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part, trim_b, trim);
+#define ZS(DT, ADT)                                                                                                  \
+  hipLaunchKernelGGL((zscore_apply_kernel<DT, ADT>), grid, dim3(ZS_T), 0, st, x, cu, H, T, part, accum, blend, trim_b, \
+                     trim, eps)
     const int adt = accum ? accum_dtype : 2;
     switch (score_dtype * 3 + adt) {
       case 0: ZS(0, 0); break;
@@ -1182,6 +1195,22 @@ extern "C" int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu
     else hipLaunchKernelGGL((fill_inf_kernel<2>), dim3(n_ranges), dim3(256), 0, st, x, prot_ranges, H, total_rows);
   }
   return check_launch();
+}
+
+extern "C" int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_segments, int H,
+                                     const void* accum, int accum_dtype, float blend, const int32_t* prot_ranges,
+                                     int n_ranges, int total_rows, void* workspace, size_t workspace_bytes,
+                                     cvllm_stream_t stream) {
+  return zscore_impl(x, score_dtype, cu, n_segments, H, accum, accum_dtype, blend, prot_ranges, n_ranges, total_rows,
+                     workspace, workspace_bytes, nullptr, 0, 0.f, stream);
+}
+
+extern "C" int cvllm_zscore_windowed(void* x, int score_dtype, const int32_t* cu, const int32_t* trim_b, int trim,
+                                     int n_segments, int H, float eps, int total_rows, void* workspace,
+                                     size_t workspace_bytes, cvllm_stream_t stream) {
+  if (trim < 0 || eps < 0.f) return CVLLM_ERR_ARG;
+  return zscore_impl(x, score_dtype, cu, n_segments, H, nullptr, 2, 0.f, nullptr, 0, total_rows, workspace,
+                     workspace_bytes, trim_b, trim, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1298,19 +1327,19 @@ extern "C" size_t cvllm_snapkv_workspace_bytes(int B, int HKV, int w, int max_se
 
 template <typename T, int D>
 static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h, float* scores,
-                    float* part, const int* cu_q, const int* cu_k, int B, int HKV, int w, int ntile, float scale,
-                    int pool, hipStream_t st) {
+                    float* part, const int* cu_q, const int* cu_k, int B, int HKV, int w, const int* w_b, int ntile,
+                    float scale, int pool, hipStream_t st) {
   const float c = scale * 1.4426950408889634f;
   dim3 grid(B * ((ntile + SK_TPW - 1) / SK_TPW) * HKV), block(256);
   float* lse = part + (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2;
 #define SNAP(G_)                                                                                                      \
   {                                                                                                                   \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,  \
-                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \
+                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool); \
     hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32) / (SK_LSE_T / 64)), dim3(SK_LSE_T), 0, st,                \
-                       (const float*)part, lse, cu_k, HKV, w, G_, ntile);                                             \
+                       (const float*)part, lse, cu_k, HKV, w, w_b, G_, ntile);                                        \
     hipLaunchKernelGGL((snapkv_kernel<T, D, G_, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
-                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, ntile, c, pool);     \
+                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool); \
   }
   switch (G) {
     case 1: SNAP(1); break;
@@ -1323,10 +1352,11 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
   return check_launch();
 }
 
-extern "C" int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
-                                   float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int B,
-                                   int HQ, int HKV, int D, int w, float sm_scale, int pool, int max_seqlen_k,
-                                   int dtype, void* workspace, size_t workspace_bytes, cvllm_stream_t stream) {
+extern "C" int cvllm_snapkv_scores_wb(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                                      float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                      const int32_t* window_b, int B, int HQ, int HKV, int D, int w, float sm_scale,
+                                      int pool, int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
+                                      cvllm_stream_t stream) {
   if (!q || !k || !scores || !cu_seqlens_q || !cu_seqlens_k) return CVLLM_ERR_ARG;
   if (B <= 0 || HQ <= 0 || HKV <= 0 || max_seqlen_k <= 0 || pool <= 0) return CVLLM_ERR_ARG;
   if (HQ % HKV != 0) return CVLLM_ERR_SHAPE;
@@ -1337,9 +1367,21 @@ extern "C" int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, i
   const int ntile = (max_seqlen_k + SK_TILE - 1) / SK_TILE;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
-  if (dtype == CVLLM_F16 && D == 128) return snapkv_g<F16, 128>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
-  if (dtype == CVLLM_F16 && D == 64) return snapkv_g<F16, 64>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
-  if (dtype == CVLLM_BF16 && D == 128) return snapkv_g<BF16, 128>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
-  if (dtype == CVLLM_BF16 && D == 64) return snapkv_g<BF16, 64>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, ntile, sm_scale, pool, st);
+#define SNAPD(T_, D_)                                                                                              \
+  return snapkv_g<T_, D_>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, window_b, \
+                          ntile, sm_scale, pool, st)
+  if (dtype == CVLLM_F16 && D == 128) SNAPD(F16, 128);
+  if (dtype == CVLLM_F16 && D == 64) SNAPD(F16, 64);
+  if (dtype == CVLLM_BF16 && D == 128) SNAPD(BF16, 128);
+  if (dtype == CVLLM_BF16 && D == 64) SNAPD(BF16, 64);
+#undef SNAPD
   return CVLLM_ERR_SHAPE;
+}
+
+extern "C" int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                                   float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int B,
+                                   int HQ, int HKV, int D, int w, float sm_scale, int pool, int max_seqlen_k,
+                                   int dtype, void* workspace, size_t workspace_bytes, cvllm_stream_t stream) {
+  return cvllm_snapkv_scores_wb(q, k, sq_n, sk_n, sk_h, scores, cu_seqlens_q, cu_seqlens_k, nullptr, B, HQ, HKV, D, w,
+                                sm_scale, pool, max_seqlen_k, dtype, workspace, workspace_bytes, stream);
 }

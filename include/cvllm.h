@@ -140,6 +140,12 @@ int cvllm_zscore_segments(void* x, int score_dtype, const int32_t* cu, int n_seg
                           const void* accum, int accum_dtype, float blend,
                           const int32_t* prot_ranges, int n_ranges, int total_rows,
                           void* workspace, size_t workspace_bytes, cvllm_stream_t stream);
+/* windowed form: replaces compression/snapkv.py:279-329 _zscore_per_batch_epilogue.  Segment s is rows
+ * [cu[s], cu[s+1] - trim_s) with trim_s = trim_b[s] (int32 [n_segments]) or `trim` when trim_b is NULL; empty
+ * segments are left alone; the variance gets `eps` added inside the square root (1e-12 upstream).            */
+int cvllm_zscore_windowed(void* x, int score_dtype, const int32_t* cu, const int32_t* trim_b, int trim,
+                          int n_segments, int H, float eps, int total_rows, void* workspace,
+                          size_t workspace_bytes, cvllm_stream_t stream);
 
 /* ---- a7: Compactor post-RoPE chunked non-causal attention mass -------------------------------
  * replaces compression/compactor.py:338-486 _non_causal_attn_kernel (+ wrapper :489-580).
@@ -178,6 +184,13 @@ int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n
                         int B, int HQ, int HKV, int D, int w, float sm_scale, int pool,
                         int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
                         cvllm_stream_t stream);
+/* the same with one window per sequence (snapkv.py:351-357: `w` may be a [B] int32 tensor): window_b[b] <= w_max,
+ * w_max * G <= 256; a sequence with window 0 is left untouched.                                              */
+int cvllm_snapkv_scores_wb(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                           float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                           const int32_t* window_b, int B, int HQ, int HKV, int D, int w_max, float sm_scale,
+                           int pool, int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
+                           cvllm_stream_t stream);
 
 /* ---- a9: joint top-k selection ------------------------------------------------------------------
  * replaces compression/common.py:171-243 scores_to_retain_indices (torch.topk full sort) and the

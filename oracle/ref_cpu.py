@@ -292,13 +292,15 @@ def compactor_post_scores(
 # --------------------------------------------------------------------------------------------
 # a8  SnapKV query-aware scores  (cv/compression/snapkv.py:39-448)
 # --------------------------------------------------------------------------------------------
-def snapkv_scores(q, k, cu_seqlens_q, cu_seqlens_k, w: int, sm_scale: Optional[float] = None,
-                  pool: int = 5, pool_tile: int = 128) -> torch.Tensor:
+def snapkv_scores(q, k, cu_seqlens_q, cu_seqlens_k, w, sm_scale: Optional[float] = None,
+                  pool: int = 5, pool_tile: int = 128, normalize: bool = False) -> torch.Tensor:
     """rows = last w queries x G heads; keys = [k_beg, k_end-w); s_j = sum_rows softmax_row(q k / sqrt D)
     over those keys only; trailing `pool`-tap mean clipped at `pool_tile` boundaries measured from the
     sequence start (:253-262; the reference tile is its autotuned BLOCK_K, pinned to 128 here,
     SURVEY P3); last w keys <- +inf (:267-276).  Sequences with L <= w are left untouched by the
-    reference (uninitialised memory, :203-205); this oracle defines them as all +inf."""
+    reference (uninitialised memory, :203-205); this oracle defines them as all +inf.
+    `w` is an int or one window per sequence (:351-357).  normalize=True: every sequence's scored rows [k_beg, k_end-w)
+    x all heads are z-scored with the biased variance and eps 1e-12 INSIDE the square root (:279-329)."""
     Nq, HQ, D = q.shape
     Nk, HKV, _ = k.shape
     G = HQ // HKV
@@ -306,7 +308,9 @@ def snapkv_scores(q, k, cu_seqlens_q, cu_seqlens_k, w: int, sm_scale: Optional[f
     out = torch.full((Nk, HKV), POS_INF, dtype=F32)
     cq = [int(x) for x in cu_seqlens_q]
     ck = [int(x) for x in cu_seqlens_k]
+    w_all = [int(w)] * (len(ck) - 1) if isinstance(w, int) else [int(x) for x in w]
     for b in range(len(ck) - 1):
+        w = w_all[b]
         kb, ke = ck[b], ck[b + 1]
         qe = cq[b + 1]
         keff = ke - w
@@ -327,6 +331,11 @@ def snapkv_scores(q, k, cu_seqlens_q, cu_seqlens_k, w: int, sm_scale: Optional[f
                 ok = idx >= lo
                 acc = acc + torch.where(ok, s[idx.clamp_min(0)], torch.zeros((), dtype=F32))
             out[kb:keff, g] = acc / (i - lo + 1).to(F32)
+        if normalize:
+            blk = out[kb:keff]
+            mean = blk.mean()
+            var = ((blk * blk).mean() - mean * mean).clamp_min(0.0)
+            out[kb:keff] = (blk - mean) / torch.sqrt(var + 1e-12)
     return out
 
 

@@ -309,6 +309,36 @@ def gen_scoring():
         save_case(name, q=q, k=k, cu_seqlens=cu, w=32, HQ=HQ, HKV=HKV, D=D, out=ref)
 
 
+def gen_snapkv_ext():
+    """SnapKV with one window per sequence and with the windowed z-score (normalize=True) - the two arguments the
+    reference's engine never uses (snapkv.py:279-329, :351-357)."""
+    for name, dtype, lens, HQ, HKV, D, w, norm in [
+        ("snapkvx_f16_wvar_norm", torch.float16, [257, 100, 600], 8, 2, 128, [32, 8, 16], True),
+        ("snapkvx_bf16_wvar", torch.bfloat16, [300, 40, 90], 16, 4, 128, [16, 32, 4], False),
+        ("snapkvx_bf16_norm", torch.bfloat16, [200, 333], 16, 4, 128, 32, True),
+    ]:
+        g = torch.Generator().manual_seed(11)
+        N = sum(lens)
+        cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+        q = torch.randn(N, HQ, D, generator=g).to(dtype)
+        k = torch.randn(N, HKV, D, generator=g).to(dtype)
+        wt = w if isinstance(w, int) else torch.tensor(w, dtype=torch.int32)
+        ref = R.sk.query_aware_key_scores(q, k, cu, cu, w=wt, normalize=norm)
+        mine = O.snapkv_scores(q, k, cu, cu, w, normalize=norm)
+        wl = [w] * len(lens) if isinstance(w, int) else w
+        ok = torch.zeros(N, dtype=torch.bool)  # rows the reference defines: sequences with L > w
+        s0 = 0
+        for L, wb in zip(lens, wl):
+            if L > wb:
+                ok[s0 : s0 + L] = True
+            s0 += L
+        fin = torch.isfinite(ref) & ok[:, None]
+        assert torch.equal(fin, torch.isfinite(mine) & ok[:, None])
+        print(f"{name}: oracle vs reference max|d| = {maxdiff(ref[fin], mine[fin]):.3e}")
+        save_case(name, q=q, k=k, cu_seqlens=cu, w=torch.tensor(wl, dtype=torch.int32), normalize=int(norm), HQ=HQ,
+                  HKV=HKV, D=D, out=ref)
+
+
 # ------------------------------------------------------------------------------------------ f-2
 def gen_producer():
     """qkv split + (Qwen3) q/k RMSNorm + RoPE as the reference's model code runs them: the reference's own RMSNorm and
@@ -359,7 +389,7 @@ def gen_producer():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring", "producer"]
+    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring", "producer", "snapkv_ext"]
     for w in which:
         {"prefill": gen_prefill, "decode": gen_decode, "stores": gen_stores, "select": gen_select,
-         "scoring": gen_scoring, "producer": gen_producer}[w]()
+         "scoring": gen_scoring, "producer": gen_producer, "snapkv_ext": gen_snapkv_ext}[w]()

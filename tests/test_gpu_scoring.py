@@ -169,6 +169,32 @@ def test_snapkv_golden(dev, name):
         s += L
 
 
+@pytest.mark.parametrize("name", list_cases("snapkvx_"))
+def test_snapkv_golden_windows_and_normalize(dev, name):
+    """`w` as a [B] tensor and normalize=True (the two arguments the reference's engine never uses) against vectors
+    of the reference, and against the same call with the windows passed one sequence at a time."""
+    from compactor_vllm_amd.compression.snapkv import query_aware_key_scores
+
+    c = load_case(name)
+    cu = c["cu_seqlens"].to(dev)
+    wl = c["w"].tolist()
+    norm = bool(c["normalize"])
+    w_arg = wl[0] if len(set(wl)) == 1 else c["w"].to(dev)
+    out = query_aware_key_scores(c["q"].to(dev), c["k"].to(dev), cu, cu, w=w_arg, normalize=norm).cpu()
+    ref = c["out"]
+    s = 0
+    for L, wb in zip(c["cu_seqlens"].diff().tolist(), wl):
+        a, r = out[s : s + L], ref[s : s + L]
+        if L > wb:
+            fin = torch.isfinite(r)
+            assert torch.equal(fin, torch.isfinite(a))
+            assert torch.allclose(a[fin], r[fin], rtol=2e-4, atol=2e-4), (a[fin] - r[fin]).abs().max()
+            assert torch.isinf(a[L - wb :]).all() and (a[L - wb :] > 0).all()
+        else:
+            assert torch.isinf(a).all()
+        s += L
+
+
 def test_snapkv_oracle_long(dev):
     from compactor_vllm_amd.compression.snapkv import query_aware_key_scores
 

@@ -172,6 +172,23 @@ def test_snapkv_oracle(name):
         s += L
 
 
+@pytest.mark.parametrize("name", list_cases("snapkvx_"))
+def test_snapkv_oracle_windows_and_normalize(name):
+    """Per-sequence windows (`w` as a [B] tensor) and the windowed z-score (normalize=True): reference vectors."""
+    c = load_case(name)
+    wl = c["w"].tolist()
+    out = O.snapkv_scores(c["q"], c["k"], c["cu_seqlens"], c["cu_seqlens"], wl, normalize=bool(c["normalize"]))
+    ref = c["out"]
+    s = 0
+    for L, wb in zip(c["cu_seqlens"].diff().tolist(), wl):
+        if L > wb:  # the reference leaves sequences with L <= w uninitialised (snapkv.py:203-205)
+            a, r = out[s : s + L], ref[s : s + L]
+            fin = torch.isfinite(r)
+            assert torch.equal(fin, torch.isfinite(a))
+            assert torch.allclose(a[fin], r[fin], rtol=2e-4, atol=2e-4), (a[fin] - r[fin]).abs().max()
+        s += L
+
+
 # ------------------------------------------------------------------------------------------ f-2
 @pytest.mark.parametrize("name", list_cases("producer_"))
 def test_producer_oracle(name):
