@@ -314,7 +314,10 @@ def snapkv_scores(q, k, cu_seqlens_q, cu_seqlens_k, w, sm_scale: Optional[float]
         kb, ke = ck[b], ck[b + 1]
         qe = cq[b + 1]
         keff = ke - w
-        if w <= 0 or keff <= kb:
+        if w <= 0:  # no window rows: an empty sum for every key (what the reference's loops leave; not in a fixture)
+            out[kb:ke] = 0.0
+            continue
+        if keff <= kb:
             continue
         for g in range(HKV):
             qq = q[qe - w : qe, g * G : (g + 1) * G].to(F32).reshape(w * G, D)
