@@ -533,6 +533,15 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   uint32_t voffk[4], voffv[4];
   int voff_kind = -1;  // 0 = cached layout, 1 = appended layout
   __amdgpu_buffer_rsrc_t rk, rv;
+  // running state of the two kinds: the current page's base (cached) / the next tile's base and the valid bytes from
+  // there to the end of the visible rows (appended) - a tile costs two 64-bit adds and a subtract, not a 64-bit multiply
+  const uint16_t* c_kp = kc + (int64_t)ld_pg * PS * D;
+  const uint16_t* c_vp = vc + (int64_t)ld_pg * PS * D;
+  const uint16_t* a_kp = k + (int64_t)s0 * sk_n + (int64_t)g * sk_h;
+  const uint16_t* a_vp = v + (int64_t)s0 * sv_n + (int64_t)g * sv_h;
+  int a_remk = la_vis > 0 ? (int)(((uint32_t)(la_vis - 1) * (uint32_t)sk_n + D) * 2) : 0;
+  int a_remv = la_vis > 0 ? (int)(((uint32_t)(la_vis - 1) * (uint32_t)sv_n + D) * 2) : 0;
+  const int a_stepk = PF_KT * (int)sk_n, a_stepv = PF_KT * (int)sv_n;  // elements per appended tile
   auto tile_desc = [&](int tt) __attribute__((always_inline)) {
     if (tt < ntc) {
       if (voff_kind != 0) {
@@ -541,14 +550,15 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int i = 0; i < 4; ++i) voffk[i] = voffv[i] = (uint32_t)(srow + 16 * i) * (D * 2) + sch * 16;
       }
       const int count = min(PF_KT, Lc - tt * PF_KT);  // > 0
-      const int64_t rowbase = (int64_t)ld_pg * PS + ld_po;  // int64 row offset (reference :371)
-      rk = __builtin_amdgcn_make_buffer_rsrc((void*)(kc + rowbase * D), 0, count * D * 2, 0x00020000);
-      rv = __builtin_amdgcn_make_buffer_rsrc((void*)(vc + rowbase * D), 0, count * D * 2, 0x00020000);
+      rk = __builtin_amdgcn_make_buffer_rsrc((void*)(c_kp + ld_po * D), 0, count * D * 2, 0x00020000);
+      rv = __builtin_amdgcn_make_buffer_rsrc((void*)(c_vp + ld_po * D), 0, count * D * 2, 0x00020000);
       ld_po += PF_KT;
       if (ld_po >= PS) {
         ld_po = 0;
         ld_pi += 1;
         ld_pg = pt[min(ld_pi, NLP - 1)];
+        c_kp = kc + (int64_t)ld_pg * PS * D;  // int64 row offset (reference :371)
+        c_vp = vc + (int64_t)ld_pg * PS * D;
       }
     } else {
       if (voff_kind != 1) {
@@ -559,14 +569,14 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
           voffv[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sv_n * 2 + sch * 16;
         }
       }
-      const int j0 = (tt - ntc) * PF_KT;
-      const int count = min(PF_KT, la_vis - j0);  // <= 0 for tiles past the last one: nothing is fetched
-      const uint16_t* kg = k + (int64_t)(s0 + j0) * sk_n + (int64_t)g * sk_h;
-      const uint16_t* vg = v + (int64_t)(s0 + j0) * sv_n + (int64_t)g * sv_h;
-      rk = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)kg, 0, count > 0 ? (int)(((uint32_t)(count - 1) * (uint32_t)sk_n + D) * 2) : 0, 0x00020000);
-      rv = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)vg, 0, count > 0 ? (int)(((uint32_t)(count - 1) * (uint32_t)sv_n + D) * 2) : 0, 0x00020000);
+      // valid bytes reach to the END of the visible rows (the four row offsets cover 64 rows anyway); tiles past the
+      // last one have nothing left: every row out of range, nothing is fetched
+      rk = __builtin_amdgcn_make_buffer_rsrc((void*)a_kp, 0, max(a_remk, 0), 0x00020000);
+      rv = __builtin_amdgcn_make_buffer_rsrc((void*)a_vp, 0, max(a_remv, 0), 0x00020000);
+      a_kp += a_stepk;
+      a_vp += a_stepv;
+      a_remk -= 2 * a_stepk;
+      a_remv -= 2 * a_stepv;
     }
   };
   auto gload_piece = [&](int set, int i) __attribute__((always_inline)) {
@@ -619,7 +629,6 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   };
 
   float psum[2] = {0.f, 0.f}, mx_raw[2] = {-INFINITY, -INFINITY}, mx_new[2] = {0.f, 0.f};
-  bool take[2] = {false, false};
   u32x4 pw[2][2];   // P fragments of the current unit [query block][keys 0-15 / 16-31]
   s16x8 kfr[4], vfr[4];  // fragment rings: reads run three fragments ahead of their MFMAs
 
@@ -681,10 +690,7 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   // (O, l; no P is pending at the decision) is scaled exactly once.  P4_THR = 0 is the textbook rule.  The running
   // max starts at a large negative FINITE value: no -inf special case on the common path (3 VALU per query block and
   // unit), a row's first visible key always takes, and exp2(-inf c + 1e30) of a masked logit is still 0.
-  auto chain = [&](int qb) __attribute__((always_inline)) {
-    mx_new[qb] = mx_raw[qb] * scale_log2e;
-    take[qb] = mx_new[qb] - m_run[qb] > (float)P4_THR;
-  };
+  auto chain = [&](int qb) __attribute__((always_inline)) { mx_new[qb] = mx_raw[qb] * scale_log2e; };
   // mask of unit (t, kb), rare: key kk of the unit is visible to this lane's query iff kk < lim.  Branch-free integer
   // form (sign mask): a compare per logit would put dozens of lane masks into SGPR pairs at once.
   auto unit_needs_mask = [&](int t, int kb) __attribute__((always_inline)) {
@@ -709,11 +715,14 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   };
   auto rescale_if_grew = [&]() __attribute__((always_inline)) {
-    if (__any(take[0] || take[1])) {  // rare: some row of the wave moves its running max
+    // a fully masked unit has mx_new = -inf: never taken
+    const bool t0 = mx_new[0] - m_run[0] > (float)P4_THR, t1 = mx_new[1] - m_run[1] > (float)P4_THR;
+    if (__builtin_amdgcn_ballot_w64(t0 || t1) != 0) {  // rare: some row of the wave moves its running max
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        const float alpha = take[qb] ? __builtin_amdgcn_exp2f(m_run[qb] - mx_new[qb]) : 1.f;
-        m_run[qb] = take[qb] ? mx_new[qb] : m_run[qb];
+        const bool take = qb ? t1 : t0;
+        const float alpha = take ? __builtin_amdgcn_exp2f(m_run[qb] - mx_new[qb]) : 1.f;
+        m_run[qb] = take ? mx_new[qb] : m_run[qb];
         l_run[qb] *= alpha;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -918,9 +927,10 @@ static int launch_prefill(const void* q, const void* k, const void* v, int64_t s
   constexpr int BM = PF_ROWS / G;
   const int nqt = (max_seqlen_q + BM - 1) / BM;
   if constexpr (D == 128) {
-    // 4-wave structure unless a 64-key tile would straddle pages (page size not a multiple of 64), the caller's row
-    // strides do not fit its 32-bit buffer offsets, or CVLLM_PREFILL=8wave
-    if (!prefill_force_8wave() && PS % PF_KT == 0 && sk_n * 2 * 64 < 0x7fffffffLL && sv_n * 2 * 64 < 0x7fffffffLL) {
+    // 4-wave structure unless a 64-key tile would straddle pages (page size not a multiple of 64), a sequence's
+    // appended block does not fit the kernel's 31-bit buffer byte counts, or CVLLM_PREFILL=8wave
+    if (!prefill_force_8wave() && PS % PF_KT == 0 && sk_n * 2 * ((int64_t)max_seqlen_q + 64) < 0x7fffffffLL &&
+        sv_n * 2 * ((int64_t)max_seqlen_q + 64) < 0x7fffffffLL) {
       auto kern4 = prefill_attn_w4_kernel<T, G>;
       set_dyn_lds_once(kern4, P4_SMEM);
       hipLaunchKernelGGL(kern4, dim3(nqt * B * HKV), dim3(P4_THREADS), P4_SMEM, st, (const uint16_t*)q,
