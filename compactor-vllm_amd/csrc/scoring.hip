@@ -123,6 +123,7 @@ __global__ void fill_inf_kernel(void* __restrict__ x, const int* __restrict__ ra
 //   Same fragments for both passes, only the operand order swaps.
 // =====================================================================================================
 constexpr int CM_CHUNK = 128;
+constexpr int CM_SMEM = CM_CHUNK * 256 + 4 * 32 * 256 + 4 * 32 * 4;
 #ifndef CM_OCC
 #define CM_OCC 2
 #endif
@@ -136,9 +137,13 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   constexpr int KS = D / 16;
   constexpr int CH = D / 8;
   constexpr int QB = G;  // 32-row query blocks per wave: rows = 128*G over 4 waves
-  __shared__ __attribute__((aligned(16))) char s_k[CM_CHUNK * 256];
-  __shared__ float s_mass[4][CM_CHUNK];
-  __shared__ __attribute__((aligned(16))) float s_lse[4][32];
+  // dynamic LDS (CM_SMEM = 66,048 B, over the static limit): K tile | one 32-row Q tile per wave | row LSEs; the
+  // per-wave column sums reuse the Q tiles after the loop
+  extern __shared__ __attribute__((aligned(16))) char cm_smem[];
+  char* s_k = cm_smem;                                                        // [CM_CHUNK * 256]
+  char* s_q = cm_smem + CM_CHUNK * 256;                                       // [4][32 * 256]
+  float(*s_lse)[32] = reinterpret_cast<float(*)[32]>(cm_smem + CM_CHUNK * 256 + 4 * 32 * 256);  // [4][32]
+  float(*s_mass)[CM_CHUNK] = reinterpret_cast<float(*)[CM_CHUNK]>(s_q);       // [4][CM_CHUNK]
 
   const int bid = blockIdx.x;
   const int g = bid % HKV;
@@ -160,17 +165,33 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   }
   __syncthreads();
 
-  float colsum[4] = {0.f, 0.f, 0.f, 0.f};  // key = kb*32 + r, this lane's half of the query rows
-  // Q fragments of a 32-row query block (row in [0, 128*G): head = row / 128, token = row % 128); the NEXT block's are in
-  // flight while a block is processed (the loads are 32-byte pieces of rows 8 KB apart: latency, not bandwidth)
-  uint4 qn[KS];
-  auto load_q = [&](int qb) __attribute__((always_inline)) {
-    const int row = (wave * QB + qb) * 32 + r;
-    const int head = row / CM_CHUNK, tok = row % CM_CHUNK;
-    const bool valid_q = tok < M;
-    const uint16_t* qp = q + (size_t)(s0 + t0 + (valid_q ? tok : 0)) * sq_n + (size_t)(g * G + head) * D + 8 * h;
+  // K fragments (A operand of pass 1, B operand of pass 2: the same layout) come from LDS in batches of one 32-key
+  // block (8 reads), the NEXT block's batch issued before the current block's 8 MFMAs: read one fragment ahead of
+  // every MFMA (what hipcc schedules by itself) the loop ran at LDS latency - 64 reads of ~ 120 cycles per query
+  // block; all 32 fragments resident (128 registers) spilled.  Step st = 4 * pass + kb uses ring slot st & 1.
+  s16x8 kf[2][KS];
+  auto load_kf = [&](int slot, int kb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qn[s] = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < KS; ++s) kf[slot][s] = *reinterpret_cast<const s16x8*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+  };
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};  // key = kb*32 + r, this lane's half of the query rows
+  // Q rows of a 32-row query block (row in [0, 128*G): head = row / 128, token = row % 128) are fetched as WHOLE rows
+  // (a wave instruction = 64 / CH rows of D*2 contiguous bytes) and turned into MFMA fragments through a wave-private
+  // LDS tile with the K tile's swizzle; the NEXT block's rows are in flight while a block is processed.  (Loading
+  // the fragments straight from global memory is 32-byte pieces of rows 8 KB apart: 117 us for 336 MB.)
+  constexpr int RPI = 64 / CH;   // rows per load instruction
+  constexpr int NI = 32 / RPI;   // load instructions per 32-row block
+  uint4 qn[NI];
+  char* s_qw = s_q + wave * (32 * 256);
+  const int lrow = lane / CH, lch = lane % CH;
+  auto load_q = [&](int qb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int row = (wave * QB + qb) * 32 + RPI * j + lrow;
+      const int head = row / CM_CHUNK, tok = row % CM_CHUNK;
+      qn[j] = tok < M ? *reinterpret_cast<const uint4*>(q + (size_t)(s0 + t0 + tok) * sq_n + (size_t)(g * G + head) * D + 8 * lch)
+                      : make_uint4(0, 0, 0, 0);
+    }
   };
   load_q(0);
 #pragma unroll 1
@@ -178,23 +199,25 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
     const int row = (wave * QB + qb) * 32 + r;
     const int tok = row % CM_CHUNK;
     const bool valid_q = tok < M;
-    s16x8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = __builtin_bit_cast(s16x8, qn[s]);
+    for (int j = 0; j < NI; ++j) *reinterpret_cast<uint4*>(s_qw + ktile_off(RPI * j + lrow, lch)) = qn[j];
     if (qb + 1 < QB) load_q(qb + 1);
+    load_kf(0, 0);
+    s16x8 qf[KS];  // the wave reads back only what it wrote itself: LDS operations of one wave execute in order
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const s16x8*>(s_qw + ktile_off(r, 2 * s + h));
     // pass 1: queries on lanes; row max / row sum folded over the four 32-key blocks (online: one block of logits
-    // live at a time - holding all four cost 48 registers and, with the Q prefetch, spills)
+    // live at a time).  (Issuing a step's MFMAs before the previous step's VALU work, with two accumulators, measured
+    // 109 us against 101: the register pressure costs more than the overlap gives at two waves per SIMD.)
     float mx = -INFINITY, sum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      load_kf((kb + 1) & 1, (kb + 1) & 3);  // steps 0-3: slot kb & 1 now, kb + 1 (or pass 2's block 0) next
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-        acc = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[s], acc);
-      }
+      for (int s = 0; s < KS; ++s) acc = mfma32s<T>(kf[kb & 1][s], qf[s], acc);
       if (M < CM_CHUNK) {  // workgroup-uniform: only a sequence's last chunk has keys to mask
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -218,35 +241,31 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
     // lse in the exp2 domain; invalid query rows get +inf so that they contribute p = 0 in pass 2
     const float lse2 = valid_q ? mx + __builtin_amdgcn_logf(sum) : INFINITY;  // v_log_f32 = log2
     // the block's 32 row values through LDS (wave-private): pass 2 needs the lse of query rows 8 j + 4 h + 0..3, four
-    // consecutive floats per accumulator quad - 4 ds_read_b128 per block instead of 64 ds_bpermute
+    // consecutive floats per accumulator quad - 4 ds_read_b128 per step instead of 16 ds_bpermute
     if (h == 0) s_lse[wave][r] = lse2;
-    float4 l4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) l4[j] = *reinterpret_cast<const float4*>(&s_lse[wave][8 * j + 4 * h]);
 
-    // pass 2: keys on lanes, query rows in the accumulator registers.  The K fragments are read from LDS AGAIN (offset
-    // laundered): hipcc otherwise keeps all 32 fragments of pass 1 alive for pass 2 - 128 registers
-    uint32_t koff = 0;
-    asm volatile("" : "+v"(koff));
+    // pass 2: keys on lanes, query rows in the accumulator registers
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       f32x16 a2;
 #pragma unroll
       for (int i = 0; i < 16; ++i) a2[i] = 0.f;
+      if (kb < 3) load_kf((kb + 1) & 1, kb + 1);  // steps 4-6 fetch the next block; block 0 is re-read per query block
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const uint4 a = *reinterpret_cast<const uint4*>(s_k + koff + ktile_off(kb * 32 + r, 2 * s + h));
-        a2 = mfma32s<T>(qf[s], __builtin_bit_cast(s16x8, a), a2);
-      }
+      for (int s = 0; s < KS; ++s) a2 = mfma32s<T>(qf[s], kf[kb & 1][s], a2);
       float cs = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {  // register i holds query row (i & 3) + 8 (i >> 2) + 4 h
-        const float l2 = (i & 3) == 0 ? l4[i >> 2].x : (i & 3) == 1 ? l4[i >> 2].y : (i & 3) == 2 ? l4[i >> 2].z : l4[i >> 2].w;
-        cs += __builtin_amdgcn_exp2f(fmaf(a2[i], scale_log2e, -l2));
+      for (int j = 0; j < 4; ++j) {  // registers 4 j .. 4 j + 3 hold query rows 8 j + 4 h + 0..3
+        const float4 l4 = *reinterpret_cast<const float4*>(&s_lse[wave][8 * j + 4 * h]);
+        cs += __builtin_amdgcn_exp2f(fmaf(a2[4 * j], scale_log2e, -l4.x));
+        cs += __builtin_amdgcn_exp2f(fmaf(a2[4 * j + 1], scale_log2e, -l4.y));
+        cs += __builtin_amdgcn_exp2f(fmaf(a2[4 * j + 2], scale_log2e, -l4.z));
+        cs += __builtin_amdgcn_exp2f(fmaf(a2[4 * j + 3], scale_log2e, -l4.w));
       }
       colsum[kb] += cs;
     }
   }
+  __syncthreads();  // every wave is done with its Q tile: the tiles become s_mass
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
     const float v = colsum[kb] + __shfl_xor(colsum[kb], 32, 64);
@@ -1219,9 +1238,13 @@ static int chunk_mass_g(int G, const void* q, const void* k, int64_t sq_n, int64
                         const int* cu, int B, int HKV, int nchunk, float scale, hipStream_t st) {
   const float c = scale * 1.4426950408889634f, pu = 1.0f / (float)CM_CHUNK;
   dim3 grid(B * nchunk * HKV), block(256);
-#define CM(G_)                                                                                                     \
-  hipLaunchKernelGGL((chunk_mass_kernel<T, D, G_>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, \
-                     sk_n, sk_h, mass, cu, B, HKV, nchunk, c, pu)
+#define CM(G_)                                                                                                       \
+  {                                                                                                                    \
+    auto kern = chunk_mass_kernel<T, D, G_>;                                                                           \
+    set_dyn_lds_once(kern, CM_SMEM);                                                                                   \
+    hipLaunchKernelGGL(kern, grid, block, CM_SMEM, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, sk_n, sk_h, mass, \
+                       cu, B, HKV, nchunk, c, pu);                                                                     \
+  }
   switch (G) {
     case 1: CM(1); break;
     case 2: CM(2); break;
