@@ -39,6 +39,8 @@ def test_prefill_golden(dev, name):
     (2, 32, 8, 128, 256, 300, [1, 513]),         # append_len == 1 (reference fast path) + multi-tile
     (3, 8, 8, 128, 128, 140, [64, 65, 2]),       # G = 1
     (2, 16, 2, 64, 128, 200, [130, 70]),         # G = 8, D = 64
+    (2, 16, 2, 128, 128, 200, [130, 70]),        # G = 8, D = 128 (4-wave kernel: a query block = one head x 32 tokens)
+    (1, 4, 4, 128, 256, 513, [300]),             # G = 1, D = 128, cached prefix longer than the appended block
     (2, 8, 4, 128, 128, 260, [256, 300]),        # G = 2
     (2, 32, 8, 128, 32, 150, [70, 200]),         # PS = 32: a 64-key tile spans two pages (per-row page lookup path)
     (2, 16, 4, 128, 96, 300, [130, 257]),        # PS = 96: tiles straddle page boundaries at varying offsets
