@@ -1039,31 +1039,34 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
       const int row = qb * 32 + r;
       const bool valid_q = row < rows_b;
       if (!PASS2) {
-        float mx = -INFINITY;
-        f32x16 acc[4];
+        // row max / row sum folded online over the tile's four 32-key blocks: one block of logits live at a time
+        // (all four = 48 more registers: 292 in all, one workgroup per CU)
+        float mx = -INFINITY, sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
+          f32x16 acc;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-            acc[kb] = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[jq][s], acc[kb]);
+            acc = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[jq][s], acc);
           }
+          float bm = -INFINITY;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float val = kk < M ? acc[kb][i] * scale_log2e : -INFINITY;
-            acc[kb][i] = val;
-            mx = fmaxf(mx, val);
+            acc[i] = kk < M ? acc[i] * scale_log2e : -INFINITY;
+            bm = fmaxf(bm, acc[i]);
           }
+          bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+          const float mn = fmaxf(mx, bm);  // key 0 of a tile is always valid (tile0 < ntile): finite from block 0 on
+          float bs = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) bs += __builtin_amdgcn_exp2f(acc[i] - mn);
+          sum = sum * __builtin_amdgcn_exp2f(mx - mn) + bs;
+          mx = mn;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(acc[kb][i] - mx);
         sum += __shfl_xor(sum, 32, 64);
         if (h == 0 && valid_q) {
           float* pp = part + ((((size_t)b * HKV + g) * ntile_max + tile) * (SK_MAXQB * 32) + row) * 2;
