@@ -42,6 +42,10 @@ __device__ __forceinline__ f32x16 mfma32<BF16>(s16x8 a, s16x8 b, f32x16 c) {
                                                  0);
 }
 
+// rescale threshold of both kernels, exp2 domain (probabilities reach at most 2^PF_THR; 0 = the textbook rule)
+#ifndef PF_THR
+#define PF_THR 8
+#endif
 constexpr int PF_ROWS = 256;   // query rows per workgroup
 constexpr int PF_KT = 64;      // keys per tile
 constexpr int PF_THREADS = 512;
@@ -283,12 +287,16 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
     // The unmasked max was computed next to the previous tile's PV MFMAs; masked tiles (rare) redo it here.
     if (need_mask) mx_raw = tile_max(sc0, sc1);
     const float mx = mx_raw * scale_log2e;
-    const float m_new = fmaxf(m_run, mx);
+    // Deferred rescale (MI355X guide T13; the decision sits before the tile's exp work and after the previous tile's
+    // PV, so no P is pending): the running max follows the row max only once it has grown by more than PF_THR in
+    // the exp2 domain.  A row's first finite max always takes (-inf + PF_THR = -inf); a row that is still all -inf never
+    // does, and no NaN is formed on the way (the file is built with -fno-honor-nans).
+    const bool grew = mx > m_run + (float)PF_THR;
+    const float m_new = grew ? mx : m_run;
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const bool grew = m_new > m_run;  // per query; rescale O only when some query of the wave saw a new max
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
     m_run = m_new;
-    if (__any(grew)) {  // exact: alpha == 1 for every lane otherwise (T13 with threshold 0)
+    if (__any(grew)) {  // alpha == 1 for every lane otherwise
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -395,16 +403,13 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
 //     their LDS writes, three LDS buffers each for K and V;
 //   * same LDS images and fragment addressing as the 8-wave kernel; the softmax differs in two documented ways: the
 //     running max is updated per 32-key unit (not per 64-key tile) and follows the row max only after it has grown
-//     by more than P4_THR (deferred rescale).  Both kernels meet the attention tolerance of the parity tests
+//     by more than PF_THR (deferred rescale).  Both kernels meet the attention tolerance of the parity tests
 //     (tests/test_gpu_prefill.py runs every case on both).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-// tunables (A/B builds pass -D): VALU issue cycles of exp work dealt to one MFMA shadow; rescale threshold (exp2 domain)
+// tunable (A/B builds pass -D): VALU issue cycles of exp work dealt to one MFMA shadow
 #ifndef P4_CAP
 #define P4_CAP 24
-#endif
-#ifndef P4_THR
-#define P4_THR 8
 #endif
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E, typename F>
@@ -684,10 +689,10 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   };
   // running-max bookkeeping of the NEXT unit for one query block (its logits' row max is in mx_raw).
   // Deferred rescale (MI355X guide T13): the running max follows the row max only once it has grown by more than
-  // P4_THR in the exp2 domain, so probabilities reach at most 2^P4_THR instead of 1 - bf16 / fp16 keep their relative
+  // PF_THR in the exp2 domain, so probabilities reach at most 2^PF_THR instead of 1 - bf16 / fp16 keep their relative
   // precision there and the fp32 sums have the headroom - and the 128-register rescale of O becomes rare (with an
   // exact running max some row of a wave grows in every 5th unit of random data).  Every quantity at the old scale
-  // (O, l; no P is pending at the decision) is scaled exactly once.  P4_THR = 0 is the textbook rule.  The running
+  // (O, l; no P is pending at the decision) is scaled exactly once.  PF_THR = 0 is the textbook rule.  The running
   // max starts at a large negative FINITE value: no -inf special case on the common path (3 VALU per query block and
   // unit), a row's first visible key always takes, and exp2(-inf c + 1e30) of a masked logit is still 0.
   auto chain = [&](int qb) __attribute__((always_inline)) { mx_new[qb] = mx_raw[qb] * scale_log2e; };
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   };
   auto rescale_if_grew = [&]() __attribute__((always_inline)) {
     // a fully masked unit has mx_new = -inf: never taken
-    const bool t0 = mx_new[0] - m_run[0] > (float)P4_THR, t1 = mx_new[1] - m_run[1] > (float)P4_THR;
+    const bool t0 = mx_new[0] - m_run[0] > (float)PF_THR, t1 = mx_new[1] - m_run[1] > (float)PF_THR;
     if (__builtin_amdgcn_ballot_w64(t0 || t1) != 0) {  // rare: some row of the wave moves its running max
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
