@@ -937,30 +937,63 @@ constexpr size_t LV_FUSED_SMEM =
 
 // =====================================================================================================
 // a8: SnapKV.  rows = last w queries x G heads of a sequence; keys = [0, L-w).
-//   K1 (grid b, g, key tile of 128): partial (max, sum) of every window row over the tile's keys.
-//   K2 (same grid): combine the partials to the exact lse of every row, recompute the tile's logits with the
-//       key on the lane, sum exp2(s - lse) over rows -> raw score of every key of the tile, then the
-//       trailing 5-tap mean clipped at the tile start (the reference's BLOCK_K, pinned to 128).
+//   K1 (grid b, g, group of SK_TPW key tiles of 128): (max, sum) of every window row over the group's keys.
+//   K2 (same grid): recompute the group's logits with the key on the lane, sum exp2(s - lse) over rows -> raw score
+//       of every key, then the trailing 5-tap mean clipped at the tile start (the reference's BLOCK_K, pinned to 128).
+//   Between them snapkv_lse_kernel folds the groups' partials into the exact lse of every row.
+// Where a pass's ~24 us go at 1 x 32 K x 8, w = 32 (profiles/r02_snapkv_phase_stamps.txt: s_memrealtime of all 512
+// workgroups, and A/B builds): the whole grid is resident at once and asks for Q + three K tiles per workgroup at its
+// start (48 MB outstanding), so the FIRST tile is usable only after ~7 us whatever the issue order; the 83 MB of a pass
+// (K 67 MB + Q 16 MB re-read per workgroup) stream in ~12.5 us (a build without the MFMA / exp work: 13.4 us); the four
+// tiles of a workgroup then compute back to back at 1.8-3.5 us per tile and the slowest workgroup exits 21 us in.
+// Deeper prefetch (1 / 2 / 3 tiles), K fragments in batches, half the VALU work per logit in pass 1 and one barrier per
+// tile instead of three each left the kernel time unchanged (23.4-24 us): the pass is a burst of memory latency
+// followed by a dependent per-workgroup compute chain, not a bandwidth or an issue bound.  Kept from those
+// experiments because they are simpler or cheaper: per-block max with the scale folded into the exp argument and the
+// key mask only on a sequence's last tile (3.5 VALU per logit instead of 7.4), row state carried over the group's
+// tiles (four times fewer partials), the K tile double-buffered in LDS (one barrier per tile), pass 2's column sums
+// parked in LDS and pooled / stored once per workgroup.
 // =====================================================================================================
+__device__ __forceinline__ float sk_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// -DCVLLM_SC_TS (debug builds of tools/dbg only): thread 0 of every workgroup records s_memrealtime (100 MHz, one
+// clock for all CUs) at phase boundaries.  Not compiled into libcvllm_hip.so.
+#ifdef CVLLM_SC_TS
+__device__ unsigned long long g_sc_rt[1024 * 16];
+#define SC_RT(i)                                                                                                   \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_sc_rt[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
+#else
+#define SC_RT(i) \
+  do {           \
+  } while (0)
+#endif
 constexpr int SK_TILE = 128;
 constexpr int SK_MAXQB = 8;  // 32-row query blocks (w*G <= 256)
-constexpr int SK_TPW = 4;    // consecutive key tiles per workgroup (Q fragments loaded once, next K tile prefetched)
-template <typename T, int D, int G, bool PASS2>
-__global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
-                                                     int64_t sq_n, int64_t sk_n, int64_t sk_h,
-                                                     float* __restrict__ scores, float* __restrict__ part,
-                                                     const float* __restrict__ lse,
-                                                     const int* __restrict__ cu_q, const int* __restrict__ cu_k,
-                                                     int B, int HKV, int w_max, const int* __restrict__ w_b,
-                                                     int ntile_max, float scale_log2e,
-                                                     int pool) {
+constexpr int SK_TPW = 4;    // consecutive key tiles per workgroup (Q fragments loaded once)
+constexpr int SK_TILE_BYTES = SK_TILE * 256;
+constexpr size_t SK_SMEM = 2 * SK_TILE_BYTES + 4 * SK_TPW * SK_TILE * sizeof(float) + SK_MAXQB * 32 * sizeof(float);
+
+// NJQ = 32-row query blocks per wave (1: w*G <= 128, 2: up to 256)
+template <typename T, int D, int G, int NJQ, bool PASS2>
+__global__ __launch_bounds__(256, 2) void snapkv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                        int64_t sq_n, int64_t sk_n, int64_t sk_h,
+                                                        float* __restrict__ scores, float* __restrict__ part,
+                                                        const float* __restrict__ lse,
+                                                        const int* __restrict__ cu_q, const int* __restrict__ cu_k,
+                                                        int B, int HKV, int w_max, const int* __restrict__ w_b,
+                                                        int ntile_max, float scale_log2e,
+                                                        int pool) {
   constexpr int KS = D / 16;
   constexpr int CH = D / 8;
   constexpr int KPT = SK_TILE * CH / 256;  // 16-byte chunks of a K tile per thread
-  __shared__ __attribute__((aligned(16))) char s_k[SK_TILE * 256];
-  __shared__ float s_col[4][SK_TILE];
-  __shared__ float s_lse[SK_MAXQB * 32];
+  constexpr int PF = NJQ == 1 ? 2 : 1;     // K tiles in flight in registers behind the one being staged
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  char* s_k = sk_smem;                                                       // [2][SK_TILE_BYTES]
+  float* s_col = reinterpret_cast<float*>(sk_smem + 2 * SK_TILE_BYTES);      // [4 waves][SK_TPW * SK_TILE]
+  float* s_lse = s_col + 4 * SK_TPW * SK_TILE;                               // [SK_MAXQB * 32]
 
+  SC_RT(PASS2 ? 8 : 0);
   const int ngrp_max = (ntile_max + SK_TPW - 1) / SK_TPW;
   const int bid = blockIdx.x;
   const int g = bid % HKV;
@@ -988,33 +1021,30 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
   const int rows_b = w * G;
   const int nqb = (rows_b + 31) / 32;
 
-  uint4 kreg[KPT];
-  auto gload = [&](int tile) {
+  uint4 kreg[PF][KPT];  // register ring; every index is a constant once the tile loop is unrolled
+  auto gload = [&](int slot, int tile) {
     const int t0 = tile * SK_TILE, M = min(SK_TILE, keff - t0);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int e = tid + 256 * j, row = e / CH, ch = e % CH;
-      kreg[j] = make_uint4(0, 0, 0, 0);
-      if (row < M) kreg[j] = *reinterpret_cast<const uint4*>(k + (size_t)(kb0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
+      kreg[slot][j] = make_uint4(0, 0, 0, 0);
+      if (row < M)
+        kreg[slot][j] = *reinterpret_cast<const uint4*>(k + (size_t)(kb0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int slot, int buf) {
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int e = tid + 256 * j;
-      *reinterpret_cast<uint4*>(s_k + ktile_off(e / CH, e % CH)) = kreg[j];
+      *reinterpret_cast<uint4*>(s_k + buf * SK_TILE_BYTES + ktile_off(e / CH, e % CH)) = kreg[slot][j];
     }
   };
-  gload(tile0);
-  if (PASS2) {
-    // exact lse of every window row: reduced over the tiles ONCE per (b, g) by snapkv_lse_kernel
-    const float* lp = lse + ((size_t)b * HKV + g) * (SK_MAXQB * 32);
-    for (int row = tid; row < nqb * 32; row += 256) s_lse[row] = row < rows_b ? lp[row] : INFINITY;
-  }
-  // this wave's query blocks (qb = wave, wave + 4): fragments stay in registers for all tiles of the workgroup
-  s16x8 qf[2][KS];
+  // this wave's query blocks (qb = wave, wave + 4): fragments stay in registers for all tiles of the workgroup.
+  // Issued BEFORE the K tiles: everything a workgroup asks for at its start arrives in about issue order while the whole
+  // grid's first requests (48 MB) queue at the memory - with Q behind two K tiles the first MFMA waited 6.7 us
+  s16x8 qf[NJQ][KS];
 #pragma unroll
-  for (int jq = 0; jq < 2; ++jq) {
+  for (int jq = 0; jq < NJQ; ++jq) {
     const int row = (wave + 4 * jq) * 32 + r;  // window row -> (query offset, local head): row = qoff*G + hq_local
     const bool valid_q = row < rows_b;
     const int qoff = row / G, hql = row % G;
@@ -1025,104 +1055,156 @@ __global__ __launch_bounds__(256) void snapkv_kernel(const uint16_t* __restrict_
       qf[jq][s] = __builtin_bit_cast(s16x8, t);
     }
   }
-  lstore();
+  if (PASS2) {
+    // exact lse of every window row: reduced over the groups ONCE per (b, g) by snapkv_lse_kernel (also ahead of the K tiles:
+    // loads return in order)
+    const float* lp = lse + ((size_t)b * HKV + g) * (SK_MAXQB * 32);
+    for (int row = tid; row < nqb * 32; row += 256) s_lse[row] = row < rows_b ? lp[row] : INFINITY;
+  }
+  SC_RT(PASS2 ? 9 : 1);
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (tile0 + p < tile1) gload(p, tile0 + p);
+  lstore(0, 0);
+  if (tile0 + PF < tile1) gload(0, tile0 + PF);
   __syncthreads();
+  SC_RT(PASS2 ? 10 : 2);
 
-  for (int tile = tile0; tile < tile1; ++tile) {
-    if (tile + 1 < tile1) gload(tile + 1);  // in flight under this tile's MFMAs
+  // pass 1: (max, sum) of this lane's half of the keys, per query block, carried over the group's tiles
+  float mx[NJQ], sum[NJQ];
+#pragma unroll
+  for (int jq = 0; jq < NJQ; ++jq) mx[jq] = -INFINITY, sum[jq] = 0.f;
+  // pass 2: -lse of the 16 query rows this lane's accumulators hold (rows past the window: -inf -> weight 0)
+  float nlse[NJQ][16];
+  if (PASS2) {
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) nlse[jq][i] = -s_lse[(wave + 4 * jq) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+  }
+
+#pragma unroll
+  for (int ti = 0; ti < SK_TPW; ++ti) {
+    const int tile = tile0 + ti;
+    if (tile >= tile1) break;  // workgroup-uniform
     const int t0 = tile * SK_TILE, M = min(SK_TILE, keff - t0);
+    const bool full = M == SK_TILE;  // only a sequence's last tile needs the key mask
+    const char* kt = s_k + (ti & 1) * SK_TILE_BYTES;
+    // K fragments (A operand of pass 1, B operand of pass 2: the same layout) come from LDS in batches of one 32-key
+    // block, the NEXT block's batch issued before the current block's MFMAs
+    s16x8 kf[2][KS];
+    auto load_kf = [&](int slot, int kb) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        kf[slot][s] = *reinterpret_cast<const s16x8*>(kt + ktile_off(kb * 32 + r, 2 * s + h));
+    };
     float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+    load_kf(0, 0);
 #pragma unroll
-    for (int jq = 0; jq < 2; ++jq) {
-      const int qb = wave + 4 * jq;
-      if (qb >= nqb) continue;  // wave-uniform
-      const int row = qb * 32 + r;
-      const bool valid_q = row < rows_b;
-      if (!PASS2) {
-        // row max / row sum folded online over the tile's four 32-key blocks: one block of logits live at a time
-        // (all four = 48 more registers: 292 in all, one workgroup per CU)
-        float mx = -INFINITY, sum = 0.f;
+    for (int kb = 0; kb < 4; ++kb) {
+      if (kb < 3) load_kf((kb + 1) & 1, kb + 1);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          f32x16 acc;
+      for (int jq = 0; jq < NJQ; ++jq) {
+        if (wave + 4 * jq >= nqb) continue;  // wave-uniform
+        f32x16 acc;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (!PASS2) {
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-            acc = mfma32s<T>(__builtin_bit_cast(s16x8, a), qf[jq][s], acc);
+          for (int s = 0; s < KS; ++s) acc = mfma32s<T>(kf[kb & 1][s], qf[jq][s], acc);
+          // acc[i]: key kb*32 + (i & 3) + 8 (i >> 2) + 4 h, query row (wave + 4 jq) * 32 + r.  Block max on the raw
+          // logits (scale > 0), the scale folded into the exp argument; the block's (max, sum) then joins the running
+          // pair - nothing per element depends on the blocks before
+          if (!full) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < M ? acc[i] : -INFINITY;
           }
-          float bm = -INFINITY;
+          float m0 = sk_max3(acc[0], acc[1], acc[2]), m1 = sk_max3(acc[3], acc[4], acc[5]);
+          m0 = sk_max3(m0, acc[6], acc[7]), m1 = sk_max3(m1, acc[8], acc[9]);
+          m0 = sk_max3(m0, acc[10], acc[11]), m1 = sk_max3(m1, acc[12], acc[13]);
+          const float mb = sk_max3(m0, m1, fmaxf(acc[14], acc[15])) * scale_log2e;
+          const float mbs = (!full && mb == -INFINITY) ? 0.f : mb;  // a lane whose 16 keys are all past the end
+          float bs0 = 0.f, bs1 = 0.f;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int kk = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            acc[i] = kk < M ? acc[i] * scale_log2e : -INFINITY;
-            bm = fmaxf(bm, acc[i]);
+          for (int i = 0; i < 16; i += 2) {
+            bs0 += __builtin_amdgcn_exp2f(fmaf(acc[i], scale_log2e, -mbs));
+            bs1 += __builtin_amdgcn_exp2f(fmaf(acc[i + 1], scale_log2e, -mbs));
           }
-          bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-          const float mn = fmaxf(mx, bm);  // key 0 of a tile is always valid (tile0 < ntile): finite from block 0 on
-          float bs = 0.f;
+          const float mn = fmaxf(mx[jq], mb);
+          const float mns = (!full && mn == -INFINITY) ? 0.f : mn;
+          sum[jq] = sum[jq] * __builtin_amdgcn_exp2f(mx[jq] - mns) + (bs0 + bs1) * __builtin_amdgcn_exp2f(mb - mns);
+          mx[jq] = mn;
+        } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) bs += __builtin_amdgcn_exp2f(acc[i] - mn);
-          sum = sum * __builtin_amdgcn_exp2f(mx - mn) + bs;
-          mx = mn;
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        if (h == 0 && valid_q) {
-          float* pp = part + ((((size_t)b * HKV + g) * ntile_max + tile) * (SK_MAXQB * 32) + row) * 2;
-          pp[0] = mx;
-          pp[1] = sum;
-        }
-      } else {
+          for (int s = 0; s < KS; ++s) acc = mfma32s<T>(qf[jq][s], kf[kb & 1][s], acc);
+          // acc[i]: query row (wave + 4 jq) * 32 + (i & 3) + 8 (i >> 2) + 4 h, key kb*32 + r
+          float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          f32x16 a2;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) a2[i] = 0.f;
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const uint4 a = *reinterpret_cast<const uint4*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-            a2 = mfma32s<T>(qf[jq][s], __builtin_bit_cast(s16x8, a), a2);
+          for (int i = 0; i < 16; i += 2) {
+            c0 += __builtin_amdgcn_exp2f(fmaf(acc[i], scale_log2e, nlse[jq][i]));
+            c1 += __builtin_amdgcn_exp2f(fmaf(acc[i + 1], scale_log2e, nlse[jq][i + 1]));
           }
-          float cs = 0.f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int qrow = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            cs += __builtin_amdgcn_exp2f(a2[i] * scale_log2e - s_lse[qrow]);
-          }
-          colsum[kb] += cs;
+          colsum[kb] += c0 + c1;
         }
       }
     }
     if (PASS2) {
+      // both halves of the query rows (lanes l, l ^ 32), then parked per wave until the workgroup's epilogue
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const float v = colsum[kb] + __shfl_xor(colsum[kb], 32, 64);
-        if (h == 0) s_col[wave][kb * 32 + r] = v;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(colsum[kb]), __float_as_uint(colsum[kb]), false, false);
+        if (h == 0) s_col[(wave * SK_TPW + ti) * SK_TILE + kb * 32 + r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
       }
-      __syncthreads();
-      if (tid < SK_TILE) s_col[0][tid] = s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid];
-      __syncthreads();
-      if (tid < M) {
-        // causal avg-pool, kernel `pool`, clipped at the tile start (snapkv.py:253-262 with BLOCK_K = 128)
-        const int lo = max(0, tid - (pool - 1));
-        float t = 0.f;
-        for (int j = lo; j <= tid; ++j) t += s_col[0][j];
-        scores[(size_t)(kb0 + t0 + tid) * HKV + g] = t / (float)(tid - lo + 1);
-      }
-      if (tile == 0)  // last w keys <- +inf (snapkv.py:267-276)
-        for (int i = tid; i < w; i += 256) scores[(size_t)(kb0 + keff + i) * HKV + g] = INFINITY;
     }
-    __syncthreads();  // every read of this K tile (and of s_col) is done
+    // the next tile goes to the other LDS buffer (its readers passed the barrier that closed the previous iteration);
+    // its register slot is then free for the tile after the ones in flight
     if (tile + 1 < tile1) {
-      lstore();
-      __syncthreads();
+      lstore((ti + 1) % PF, (ti + 1) & 1);
+      if (tile + 1 + PF < tile1) gload((ti + 1) % PF, tile + 1 + PF);
     }
+    __syncthreads();
+    SC_RT((PASS2 ? 11 : 3) + ti);
   }
+
+  if (!PASS2) {
+    // the two key halves of a row (lanes l, l ^ 32) merged in a fixed order; one (max, sum) per row and GROUP
+#pragma unroll
+    for (int jq = 0; jq < NJQ; ++jq) {
+      const int row = (wave + 4 * jq) * 32 + r;
+      const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[jq]), __float_as_uint(mx[jq]), false, false);
+      const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[jq]), __float_as_uint(sum[jq]), false, false);
+      const float m_lo = __uint_as_float(sm[0]), m_hi = __uint_as_float(sm[1]);
+      const float mn = fmaxf(m_lo, m_hi);  // finite: key 0 of the group's first tile is valid and sits in the low half
+      const float tot = __uint_as_float(ss[0]) * __builtin_amdgcn_exp2f(m_lo - mn) +
+                        __uint_as_float(ss[1]) * __builtin_amdgcn_exp2f(m_hi - mn);
+      if (h == 0 && row < rows_b) {
+        float* pp = part + ((((size_t)b * HKV + g) * ngrp_max + grp) * (SK_MAXQB * 32) + row) * 2;
+        pp[0] = mn;
+        pp[1] = tot;
+      }
+    }
+  } else {
+    // epilogue, once per workgroup: the four waves' column sums, then the causal avg-pool, kernel `pool`, clipped
+    // at the TILE start (snapkv.py:253-262 with BLOCK_K = 128)
+    const int nk = min(keff - tile0 * SK_TILE, (tile1 - tile0) * SK_TILE);
+    constexpr int WS = SK_TPW * SK_TILE;
+    for (int i = tid; i < nk; i += 256) s_col[i] = s_col[i] + s_col[WS + i] + s_col[2 * WS + i] + s_col[3 * WS + i];
+    __syncthreads();
+    for (int i = tid; i < nk; i += 256) {
+      const int j = i % SK_TILE;
+      const int lo = max(0, j - (pool - 1));
+      float t = 0.f;
+      for (int jj = lo; jj <= j; ++jj) t += s_col[i - j + jj];
+      scores[(size_t)(kb0 + tile0 * SK_TILE + i) * HKV + g] = t / (float)(j - lo + 1);
+    }
+    if (tile0 == 0)  // last w keys <- +inf (snapkv.py:267-276)
+      for (int i = tid; i < w; i += 256) scores[(size_t)(kb0 + keff + i) * HKV + g] = INFINITY;
+  }
+  SC_RT(PASS2 ? 15 : 7);
 }
 
-// lse[b, g, row] = log2-domain log-sum-exp of window row `row` over all scored keys, from the per-tile (max, sum)
-// partials of pass 1.  One WAVE per (b, g, row): lane l folds tiles l, l + 64, ... (independent loads, fixed order),
+// lse[b, g, row] = log2-domain log-sum-exp of window row `row` over all scored keys, from the per-group (max, sum)
+// partials of pass 1.  One WAVE per (b, g, row): lane l folds groups l, l + 64, ... (independent loads, fixed order),
 // then the 64 lane states are merged by a fixed shuffle tree - reproducible.  (The first version gave a row to one
 // thread per 16-tile slice, 32 workgroups in all: 24 us of mostly exposed load latency at 256 tiles.)
 constexpr int SK_LSE_T = 256;  // 4 rows per workgroup
@@ -1135,9 +1217,10 @@ __global__ __launch_bounds__(SK_LSE_T) void snapkv_lse_kernel(const float* __res
   const int bg = gr / ROWS, row = gr % ROWS, b = bg / HKV;
   const int w = min(w_b ? w_b[b] : w_max, w_max);
   const int keff = cu_k[b + 1] - cu_k[b] - w;
-  const int ntile = keff > 0 ? (keff + SK_TILE - 1) / SK_TILE : 0;
+  const int ntile = keff > 0 ? ((keff + SK_TILE - 1) / SK_TILE + SK_TPW - 1) / SK_TPW : 0;  // groups of SK_TPW tiles
+  const int ngrp_max = (ntile_max + SK_TPW - 1) / SK_TPW;
   if (row >= w * G) return;  // wave-uniform
-  const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)bg * ntile_max * ROWS + row;
+  const float2* pp = reinterpret_cast<const float2*>(part) + (size_t)bg * ngrp_max * ROWS + row;
   float m = -INFINITY, ssum = 0.f;
   for (int t0 = lane; t0 < ntile; t0 += 4 * 64) {
     float2 ms[4];
@@ -1358,14 +1441,23 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
   const float c = scale * 1.4426950408889634f;
   dim3 grid(B * ((ntile + SK_TPW - 1) / SK_TPW) * HKV), block(256);
   float* lse = part + (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2;
+  const bool two = w * G > 128;  // query blocks per wave
+#define SNAP2(G_, NJQ_)                                                                                               \
+  {                                                                                                                   \
+    auto k1 = snapkv_kernel<T, D, G_, NJQ_, false>;                                                                   \
+    auto k2 = snapkv_kernel<T, D, G_, NJQ_, true>;                                                                    \
+    set_dyn_lds_once(k1, (int)SK_SMEM);                                                                               \
+    set_dyn_lds_once(k2, (int)SK_SMEM);                                                                               \
+    hipLaunchKernelGGL(k1, grid, block, SK_SMEM, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, sk_n, sk_h,        \
+                       scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool);                  \
+    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32) / (SK_LSE_T / 64)), dim3(SK_LSE_T), 0, st,      \
+                       (const float*)part, lse, cu_k, HKV, w, w_b, G_, ntile);                                        \
+    hipLaunchKernelGGL(k2, grid, block, SK_SMEM, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, sk_n, sk_h,        \
+                       scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool);                  \
+  }
 #define SNAP(G_)                                                                                                      \
   {                                                                                                                   \
-    hipLaunchKernelGGL((snapkv_kernel<T, D, G_, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,  \
-                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool); \
-    hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32) / (SK_LSE_T / 64)), dim3(SK_LSE_T), 0, st,                \
-                       (const float*)part, lse, cu_k, HKV, w, w_b, G_, ntile);                                        \
-    hipLaunchKernelGGL((snapkv_kernel<T, D, G_, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
-                       sq_n, sk_n, sk_h, scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool); \
+    if (two) SNAP2(G_, 2) else SNAP2(G_, 1)                                                                           \
   }
   switch (G) {
     case 1: SNAP(1); break;
@@ -1374,6 +1466,7 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
     case 8: SNAP(8); break;
     default: return CVLLM_ERR_SHAPE;
   }
+#undef SNAP2
 #undef SNAP
   return check_launch();
 }
@@ -1411,3 +1504,10 @@ extern "C" int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, i
   return cvllm_snapkv_scores_wb(q, k, sq_n, sk_n, sk_h, scores, cu_seqlens_q, cu_seqlens_k, nullptr, B, HQ, HKV, D, w,
                                 sm_scale, pool, max_seqlen_k, dtype, workspace, workspace_bytes, stream);
 }
+
+#ifdef CVLLM_SC_TS
+extern "C" void cvllm_debug_scoring_stamps(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_sc_rt), sizeof(unsigned long long) * 1024 * 16);
+}
+#endif
