@@ -22,6 +22,19 @@ __device__ __forceinline__ f32x16 mfma32s<BF16>(s16x8 a, s16x8 b, f32x16 c) {
                                                  0);
 }
 
+// -DCVLLM_SC_TS (debug builds of tools/dbg only): thread 0 of every workgroup records s_memrealtime (100 MHz, one
+// clock for all CUs) at phase boundaries.  Not compiled into libcvllm_hip.so.
+#ifdef CVLLM_SC_TS
+__device__ unsigned long long g_sc_rt[1024 * 16];
+#define SC_RT(i)                                                                                                   \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_sc_rt[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
+#else
+#define SC_RT(i) \
+  do {           \
+  } while (0)
+#endif
 __device__ __forceinline__ uint32_t ktile_off(int row, int ch) { return row * 256 + 16 * (ch ^ (row & 15)); }
 
 // =====================================================================================================
@@ -137,6 +150,8 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   constexpr int KS = D / 16;
   constexpr int CH = D / 8;
   constexpr int QB = G;  // 32-row query blocks per wave: rows = 128*G over 4 waves
+  // (Round 2, not kept: 16-row Q tiles = 49.7 KB for a third workgroup per CU - the kernel needs ~230 registers, 168 are
+  // left at three waves per SIMD: 118-150 spilled, 244 us; the same structure at two workgroups per CU: 110 us.)
   // dynamic LDS (CM_SMEM = 66,048 B, over the static limit): K tile | one 32-row Q tile per wave | row LSEs; the
   // per-wave column sums reuse the Q tiles after the loop
   extern __shared__ __attribute__((aligned(16))) char cm_smem[];
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   float(*s_lse)[32] = reinterpret_cast<float(*)[32]>(cm_smem + CM_CHUNK * 256 + 4 * 32 * 256);  // [4][32]
   float(*s_mass)[CM_CHUNK] = reinterpret_cast<float(*)[CM_CHUNK]>(s_q);       // [4][CM_CHUNK]
 
+  SC_RT(0);
   const int bid = blockIdx.x;
   const int g = bid % HKV;
   const int c = (bid / HKV) % nchunk_max;
@@ -156,24 +172,17 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
 
-  // K tile -> LDS (rows >= M zero)
-  for (int e = tid; e < CM_CHUNK * CH; e += 256) {
-    const int row = e / CH, ch = e % CH;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (row < M) val = *reinterpret_cast<const uint4*>(k + (size_t)(s0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
-    *reinterpret_cast<uint4*>(s_k + ktile_off(row, ch)) = val;
-  }
-  __syncthreads();
-
-  // K fragments (A operand of pass 1, B operand of pass 2: the same layout) come from LDS in batches of one 32-key
-  // block (8 reads), the NEXT block's batch issued before the current block's 8 MFMAs: read one fragment ahead of
-  // every MFMA (what hipcc schedules by itself) the loop ran at LDS latency - 64 reads of ~ 120 cycles per query
-  // block; all 32 fragments resident (128 registers) spilled.  Step st = 4 * pass + kb uses ring slot st & 1.
-  s16x8 kf[2][KS];
-  auto load_kf = [&](int slot, int kb) __attribute__((always_inline)) {
+  // K tile -> LDS (rows >= M zero).  The first query block's rows are requested right behind the K tile, before the
+  // tile is staged: asked for after the barrier they cost every workgroup a second exposed memory latency (query
+  // block 0 took 6.3 us against 2.9-4.6 for the others, profiles/r02_scoring_phase_stamps.txt)
+  constexpr int KPT = CM_CHUNK * CH / 256;
+  uint4 kv[KPT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) kf[slot][s] = *reinterpret_cast<const s16x8*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
-  };
+  for (int j = 0; j < KPT; ++j) {
+    const int e = tid + 256 * j, row = e / CH, ch = e % CH;
+    kv[j] = make_uint4(0, 0, 0, 0);
+    if (row < M) kv[j] = *reinterpret_cast<const uint4*>(k + (size_t)(s0 + t0 + row) * sk_n + (size_t)g * sk_h + ch * 8);
+  }
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};  // key = kb*32 + r, this lane's half of the query rows
   // Q rows of a 32-row query block (row in [0, 128*G): head = row / 128, token = row % 128) are fetched as WHOLE rows
   // (a wave instruction = 64 / CH rows of D*2 contiguous bytes) and turned into MFMA fragments through a wave-private
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   // the fragments straight from global memory is 32-byte pieces of rows 8 KB apart: 117 us for 336 MB.)
   constexpr int RPI = 64 / CH;   // rows per load instruction
   constexpr int NI = 32 / RPI;   // load instructions per 32-row block
-  uint4 qn[NI];
+  uint4 qn[NI];  // (two blocks in flight, block loop unrolled in pairs: 228-254 registers spilled - not kept)
   char* s_qw = s_q + wave * (32 * 256);
   const int lrow = lane / CH, lch = lane % CH;
   auto load_q = [&](int qb) __attribute__((always_inline)) {
@@ -194,8 +203,26 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
     }
   };
   load_q(0);
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int e = tid + 256 * j;
+    *reinterpret_cast<uint4*>(s_k + ktile_off(e / CH, e % CH)) = kv[j];
+  }
+  __syncthreads();
+  SC_RT(1);
+  // K fragments (A operand of pass 1, B operand of pass 2: the same layout) come from LDS in batches of one 32-key
+  // block (8 reads), the NEXT block's batch issued before the current block's 8 MFMAs: read one fragment ahead of
+  // every MFMA (what hipcc schedules by itself) the loop ran at LDS latency - 64 reads of ~ 120 cycles per query
+  // block; all 32 fragments resident (128 registers) spilled.  Step st = 4 * pass + kb uses ring slot st & 1.
+  s16x8 kf[2][KS];
+  auto load_kf = [&](int slot, int kb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kf[slot][s] = *reinterpret_cast<const s16x8*>(s_k + ktile_off(kb * 32 + r, 2 * s + h));
+  };
+
 #pragma unroll 1
   for (int qb = 0; qb < QB; ++qb) {
+    if (qb < 4) SC_RT(2 + qb);
     const int row = (wave * QB + qb) * 32 + r;
     const int tok = row % CM_CHUNK;
     const bool valid_q = tok < M;
@@ -265,6 +292,7 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
       colsum[kb] += cs;
     }
   }
+  SC_RT(6);
   __syncthreads();  // every wave is done with its Q tile: the tiles become s_mass
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
@@ -278,6 +306,7 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
     mass[(size_t)(s0 + t0 + tid) * HKV + g] =
         s_mass[0][tid] + s_mass[1][tid] + s_mass[2][tid] + s_mass[3][tid] + pad_rows * pad_unit;
   }
+  SC_RT(7);
 }
 
 // =====================================================================================================
@@ -721,23 +750,36 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
   const uint16_t* kh = key + (size_t)beg * s_n + (size_t)hh * s_h;
   const int w0 = wave * (32 * LV2_NB);  // first row of this wave
 
-  // key fragments of a block (A operand: lane = row r, dims 16 s + 8 h ..); rows past the chunk read as zero
-  uint4 kr[KS];
-  auto load_block = [&](int n0) __attribute__((always_inline)) {
-    const int n = n0 + r;
+  // key fragments of a block (A operand: lane = row r, dims 16 s + 8 h ..); rows past the chunk read as zero.  ALL of
+  // the wave's blocks are requested at the start, behind the PHI elements (loads return in order): with one block
+  // fetched after the previous block's MFMAs the sketch phase was four exposed memory latencies (7 us of the kernel's
+  // 53, profiles/r02_scoring_phase_stamps.txt)
+  uint4 kr[LV2_NB][KS];
+  auto load_block = [&](int b) __attribute__((always_inline)) {
+    const int n = w0 + 32 * b + r;
     const bool valid = n < L;
     const uint16_t* kp = kh + (size_t)(valid ? n : 0) * s_n + 8 * h;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) kr[s] = valid ? *reinterpret_cast<const uint4*>(kp + 16 * s) : make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < KS; ++s) kr[b][s] = valid ? *reinterpret_cast<const uint4*>(kp + 16 * s) : make_uint4(0, 0, 0, 0);
   };
-  load_block(w0);  // in flight while PHI is staged
-
+  SC_RT(0);
   // ---- PHI^T fragments (B operand of the sketch), as in sketch_kernel
-  for (int e = tid; e < LV_KMAX * D; e += LV2_T) {
-    const int col = e / D, d = e % D;
-    s_phiT[col][d] = col < kdim ? phi[(size_t)d * kdim + col] : (uint16_t)0;
+  constexpr int PV = LV_KMAX * D / LV2_T;
+  uint16_t pv[PV];
+#pragma unroll
+  for (int i = 0; i < PV; ++i) {
+    const int e = tid + LV2_T * i, col = e / D, d = e % D;
+    pv[i] = col < kdim ? phi[(size_t)d * kdim + col] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int b = 0; b < LV2_NB - 1; ++b) load_block(b);  // the last block follows the first block's MFMAs (registers)
+#pragma unroll
+  for (int i = 0; i < PV; ++i) {
+    const int e = tid + LV2_T * i;
+    s_phiT[e / D][e % D] = pv[i];
   }
   __syncthreads();
+  SC_RT(1);
   f32x16 x[LV2_NB][2];  // the wave's sketch: x[b][cb][i] = X[row w0 + 32 b + (i&3) + 8 (i>>2) + 4 h][col 32 cb + r]
   {
     s16x8 pf[2][KS];
@@ -754,10 +796,10 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
         for (int i = 0; i < 16; ++i) x[b][cb][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        x[b][0] = mfma32s<T>(__builtin_bit_cast(s16x8, kr[s]), pf[0][s], x[b][0]);
-        x[b][1] = mfma32s<T>(__builtin_bit_cast(s16x8, kr[s]), pf[1][s], x[b][1]);
+        x[b][0] = mfma32s<T>(__builtin_bit_cast(s16x8, kr[b][s]), pf[0][s], x[b][0]);
+        x[b][1] = mfma32s<T>(__builtin_bit_cast(s16x8, kr[b][s]), pf[1][s], x[b][1]);
       }
-      if (b + 1 < LV2_NB) load_block(w0 + 32 * (b + 1));
+      if (b == 0) load_block(LV2_NB - 1);
     }
   }
   // column means: lane sums its rows, + the partner half, waves combined through LDS in a fixed order
@@ -770,6 +812,7 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
     c0 += __shfl_xor(c0, 32, 64);
     c1 += __shfl_xor(c1, 32, 64);
     if (h == 0) s_part[wave * LV_KMAX + r] = c0, s_part[wave * LV_KMAX + 32 + r] = c1;
+  SC_RT(2);
     __syncthreads();  // also: every wave has its PHI fragments, s_phiT may become the tiles
     if (tid < LV_KMAX) {
       float t = 0.f;
@@ -777,6 +820,7 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
       s_mu[tid] = t / (float)L;
     }
     __syncthreads();
+  SC_RT(3);
     const float mu0 = s_mu[r], mu1 = s_mu[32 + r];
 #pragma unroll
     for (int b = 0; b < LV2_NB; ++b)
@@ -836,6 +880,7 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
       s_G[a * LV_LD + b] = t + (a == b ? reg : 0.f);
     }
     __syncthreads();
+  SC_RT(4);
   }
   // ---- 3. one wave: Cholesky in registers (lane i owns row i; column j of L is broadcast with v_readlane), W = L^-1
   if (tid < 64) {
@@ -890,6 +935,7 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
     }
   }
   __syncthreads();
+  SC_RT(5);
   // ---- 4. Y = X W^T by fp32 MFMAs, score_i = sum_j Y[i][j]^2.  B operand: B[k = c][col = j] = W[16 jb + j][c]; the
   // blocks of W right of the diagonal block are zero: column block jb needs k-steps 0 .. 4 (jb + 1) - 1 only.
   {
@@ -930,6 +976,7 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
       }
     }
   }
+  SC_RT(6);
 }
 
 constexpr size_t LV_FUSED_SMEM =
@@ -955,19 +1002,6 @@ constexpr size_t LV_FUSED_SMEM =
 // parked in LDS and pooled / stored once per workgroup.
 // =====================================================================================================
 __device__ __forceinline__ float sk_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-// -DCVLLM_SC_TS (debug builds of tools/dbg only): thread 0 of every workgroup records s_memrealtime (100 MHz, one
-// clock for all CUs) at phase boundaries.  Not compiled into libcvllm_hip.so.
-#ifdef CVLLM_SC_TS
-__device__ unsigned long long g_sc_rt[1024 * 16];
-#define SC_RT(i)                                                                                                   \
-  do {                                                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_sc_rt[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();  \
-  } while (0)
-#else
-#define SC_RT(i) \
-  do {           \
-  } while (0)
-#endif
 constexpr int SK_TILE = 128;
 constexpr int SK_MAXQB = 8;  // 32-row query blocks (w*G <= 256)
 constexpr int SK_TPW = 4;    // consecutive key tiles per workgroup (Q fragments loaded once)
