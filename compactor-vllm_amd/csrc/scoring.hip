@@ -842,7 +842,11 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
   };
   const int kq = lane >> 4, cl = lane & 15;  // fp32 MFMA 16x16x4: k index / row-or-column index of a lane's operand
 
-  // ---- 2. Gram: six 16 x 16 blocks (ja <= jb) per wave, fp32 MFMA over the tile's rows
+  // ---- 2. Gram: six 16 x 16 blocks (ja <= jb) per wave, fp32 MFMA over the tile's rows.  (Round 2, not kept: Gram
+  // straight from the accumulators - they already have the layout of both operands of v_mfma_f32_32x32x16_bf16 when
+  // k runs over rows - with the fp32 values split into bf16 terms: hi + lo (72 MFMAs) cut this phase from 9.9 to 5.8 us
+  // but leverage scores near 1 came out 1e-3 off; hi + mid + lo with six products (144 MFMAs) is fp32-exact to the
+  // strict test and gains 1.2 us - not worth a second arithmetic path.)
   {
     f32x4 g[6];
 #pragma unroll
