@@ -17,6 +17,19 @@
 
 namespace cvllm {
 
+// -DCVLLM_SEL_TS (debug builds of tools/dbg only): s_memrealtime stamps of the slice-histogram kernel, per launch slot
+#ifdef CVLLM_SEL_TS
+__device__ unsigned long long g_sel_rt[8 * 64 * 8];  // [pass slot][workgroup][stamp]
+#define SEL_RT(slot, i)                                                                                        \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 64) g_sel_rt[((slot) * 64 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define SEL_RT(slot, i) \
+  do {                  \
+  } while (0)
+#endif
+
 constexpr int SEL_T = 1024;  // threads per workgroup
 constexpr int SEL_W = SEL_T / 64;
 constexpr int SEL_MAXH = 64;
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__
   __shared__ uint32_t s_state[2];
   __shared__ int s_wsum[SJ_T / 64];
   __shared__ int s_ticket;
+  SEL_RT(pass, 0);
   const int b = blockIdx.x / NS, sl = blockIdx.x % NS;
   const int tid = threadIdx.x;
   const int n0 = cu[b];
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__
   if (beg >= n) return;
   const int end = min(n, beg + SJ_SLICE);
   const SjState s = st[b];
+  SEL_RT(pass, 1);
   const int fixed_bits = pass == 0 ? 0 : s.fixed_bits;
   if (fixed_bits >= 32) return;  // retain == 0: nothing to select
   const int bits = pass < 2 ? 12 : 8;
@@ -357,18 +372,23 @@ __global__ __launch_bounds__(SJ_T) void sj_hist_kernel(const float* __restrict__
     }
   }
   __syncthreads();
+  SEL_RT(pass, 2);
   uint32_t* g = gh + (size_t)b * SEL_BINS;
   for (int i = tid; i < (1 << bits); i += SJ_T) {
     const uint32_t c = hist[i];
     if (c) atomicAdd(&g[i], c);
   }
+  SEL_RT(pass, 3);
   // the radix step on the finished histogram, by the last slice workgroup of the sequence to arrive (this used to be
   // a launch of its own: the selection is launch-latency bound, 18 launches of ~ 4.7 us at 32 K x 8)
   const int participants = (n + SJ_SLICE - 1) / SJ_SLICE;
-  if (last_arriver(tickets + b, participants, &s_ticket)) {
+  const bool last = last_arriver(tickets + b, participants, &s_ticket);
+  SEL_RT(pass, 4);
+  if (last) {
     int rr = retain[b];
     rr = rr < 0 ? 0 : (rr > n ? n : rr);
     radix_scan_step<SJ_T>(g, st + b, rr, pass, s_state, s_wsum);
+    SEL_RT(pass, 5);
   }
 }
 
@@ -644,43 +664,19 @@ __global__ __launch_bounds__(SJ_T) void sh_hist_kernel(const float* __restrict__
 }
 
 
-// slice_cnt[(bh * P + p) * 2 + {0, 1}] = #keys above / equal to the column's threshold in slice p
-__global__ __launch_bounds__(SJ_T) void sh_count_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
-                                                        const int* __restrict__ target, const SjState* __restrict__ st,
-                                                        int* __restrict__ slice_cnt, int H, int P) {
-  __shared__ int s_wsum[SJ_T / 64];
-  const int p = blockIdx.x % P, bh = blockIdx.x / P;
-  const int b = bh / H, h = bh % H;
-  const int tid = threadIdx.x;
-  const int n0 = cu[b];
-  const int Lb = cu[b + 1] - n0;
-  const int beg = p * SH_SLICE;
-  if (Lb <= 0 || beg >= Lb) return;
-  const int t = sh_rank(target, bh, Lb);
-  if (t <= 0 || t >= Lb) return;
-  const int end = min(Lb, beg + SH_SLICE);
-  const uint32_t v = st[bh].prefix;
-  const float* base = scores + (size_t)n0 * H + h;
-  int gt = 0, eq = 0;
-  for (int i = beg + tid; i < end; i += SJ_T) {
-    const uint32_t key = order_key(base[(size_t)i * H]);
-    gt += key > v ? 1 : 0;
-    eq += key == v ? 1 : 0;
-  }
-  int tg, te;
-  (void)block_excl_scan_cnt_t<SJ_T>(gt, s_wsum, tg);
-  (void)block_excl_scan_cnt_t<SJ_T>(eq, s_wsum, te);
-  if (tid == 0) {
-    slice_cnt[((size_t)bh * P + p) * 2] = tg;
-    slice_cnt[((size_t)bh * P + p) * 2 + 1] = te;
-  }
-}
-
+// Per-slice kept counts and the ordered write in ONE launch (they were two: sh_count_kernel, sh_write_kernel).  A slice
+// workgroup counts its keys above / equal to the column's threshold (keys stay in registers), publishes the pair as one
+// flagged 64-bit word, reads the words of the slices BEFORE it in the column (look-back: those workgroups have lower
+// block ids, so the in-order dispatcher has started every one of them before this one - the wait cannot deadlock; it is
+// bounded all the same) and places its kept token indices behind theirs: the list stays ascending.
+constexpr unsigned long long SH_FLAG = 1ull << 63;
+static_assert(SH_SLICE == SJ_T * 8, "eight keys of a slice per thread");
 __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
                                                         const int* __restrict__ target, const SjState* __restrict__ st,
-                                                        const int* __restrict__ slice_cnt, int* __restrict__ kept_idx,
-                                                        int H, int P, int max_seqlen) {
+                                                        unsigned long long* __restrict__ slice_cnt,
+                                                        int* __restrict__ kept_idx, int H, int P, int max_seqlen) {
   __shared__ int s_wsum[SJ_T / 64];
+  __shared__ int s_before[2];
   const int p = blockIdx.x % P, bh = blockIdx.x / P;
   const int b = bh / H, h = bh % H;
   const int tid = threadIdx.x;
@@ -698,44 +694,68 @@ __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict_
   }
   const uint32_t v = st[bh].prefix;
   const int quota = st[bh].remaining;
-  // kept tokens and ties in the slices before this one (P <= 64: every thread walks the few counters itself)
-  int ties_before = 0, kept_before = 0;
-  for (int q = 0; q < p; ++q) {
-    const int g = slice_cnt[((size_t)bh * P + q) * 2], e = slice_cnt[((size_t)bh * P + q) * 2 + 1];
-    const int room = quota - ties_before;
-    kept_before += g + (room > 0 ? min(e, room) : 0);
-    ties_before += e;
-  }
+  // thread t owns the CONSECUTIVE tokens beg + 8 t .. + 7 (thread order = token order for the block scans)
+  constexpr int E = SH_SLICE / SJ_T;
   const float* base = scores + (size_t)n0 * H + h;
-  for (int i0 = beg; i0 < end; i0 += SJ_T * SJ_E) {
-    uint32_t key[SJ_E];
-    bool in[SJ_E];
-    int ntie = 0;
+  uint32_t key[E];
+  int gt = 0, eq = 0;
 #pragma unroll
-    for (int e = 0; e < SJ_E; ++e) {
-      const int i = i0 + tid * SJ_E + e;
-      in[e] = i < end;
-      key[e] = in[e] ? order_key(base[(size_t)i * H]) : 0u;
-      ntie += (in[e] && key[e] == v) ? 1 : 0;
-    }
-    int tot_t, tot_k;
-    int tr = ties_before + block_excl_scan_cnt_t<SJ_T>(ntie, s_wsum, tot_t);
-    bool keep[SJ_E];
-    int nkeep = 0;
-#pragma unroll
-    for (int e = 0; e < SJ_E; ++e) {
-      const bool tie = in[e] && key[e] == v;
-      keep[e] = in[e] && (key[e] > v || (tie && tr < quota));
-      tr += tie ? 1 : 0;
-      nkeep += keep[e] ? 1 : 0;
-    }
-    int slot = kept_before + block_excl_scan_cnt_t<SJ_T>(nkeep, s_wsum, tot_k);
-#pragma unroll
-    for (int e = 0; e < SJ_E; ++e)
-      if (keep[e]) list[slot++] = i0 + tid * SJ_E + e;
-    ties_before += tot_t;
-    kept_before += tot_k;
+  for (int e = 0; e < E; ++e) {
+    const int i = beg + tid * E + e;
+    key[e] = i < end ? order_key(base[(size_t)i * H]) : 0u;
+    gt += (i < end && key[e] > v) ? 1 : 0;
+    eq += (i < end && key[e] == v) ? 1 : 0;
   }
+  int tg, te;
+  const int gt_before_me = block_excl_scan_cnt_t<SJ_T>(gt, s_wsum, tg);
+  const int eq_before_me = block_excl_scan_cnt_t<SJ_T>(eq, s_wsum, te);
+  unsigned long long* col = slice_cnt + (size_t)bh * P;
+  if (tid == 0)
+    __hip_atomic_store(&col[p], SH_FLAG | ((unsigned long long)(uint32_t)tg << 31) | (unsigned long long)(uint32_t)te,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // look-back over the slices before this one (P <= 64: one thread each), then a serial fold in slice order by thread 0
+  __shared__ unsigned long long s_prev[SH_MAXP];
+  if (tid < p) {
+    unsigned long long wv = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    do {
+      wv = __hip_atomic_load(&col[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while (!(wv & SH_FLAG) && __builtin_amdgcn_s_memrealtime() - t0 < 50000000ull);  // 0.5 s at 100 MHz
+    if (!(wv & SH_FLAG)) __builtin_trap();  // cannot happen with in-order dispatch; never continue with a wrong count
+    s_prev[tid] = wv;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ties_before = 0, kept_before = 0;
+    for (int q = 0; q < p; ++q) {
+      const unsigned long long wv = s_prev[q];
+      const int g = (int)((wv >> 31) & 0x7fffffffu), e = (int)(wv & 0x7fffffffu);
+      const int room = quota - ties_before;
+      kept_before += g + (room > 0 ? min(e, room) : 0);
+      ties_before += e;
+    }
+    s_before[0] = ties_before;
+    s_before[1] = kept_before;
+  }
+  __syncthreads();
+  int tr = s_before[0] + eq_before_me;  // ties before this thread's first token, in the whole column
+  bool keep[E];
+  int nkeep = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = beg + tid * E + e;
+    const bool in = i < end;
+    const bool tie = in && key[e] == v;
+    keep[e] = in && (key[e] > v || (tie && tr < quota));
+    tr += tie ? 1 : 0;
+    nkeep += keep[e] ? 1 : 0;
+  }
+  (void)gt_before_me;
+  int tot_k;
+  int slot = s_before[1] + block_excl_scan_cnt_t<SJ_T>(nkeep, s_wsum, tot_k);
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (keep[e]) list[slot++] = beg + tid * E + e;
 }
 
 }  // namespace cvllm
@@ -743,7 +763,7 @@ __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict_
 using namespace cvllm;
 
 // workspace: target[B, H] | joint path: global histograms, states, per-head counts, tickets | per-head path: per-column
-// histograms, states, tickets, per-slice counts.  Everything up to the per-slice counts is zeroed by ONE memset.
+// histograms, states, tickets, per-slice count words.  All of it is zeroed by ONE memset.
 static size_t sel_target_bytes(int B, int H) { return ((size_t)B * H * sizeof(int32_t) + 15) / 16 * 16; }
 static size_t sel_joint_bytes(int B) {
   return (size_t)B * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 2 * SEL_MAXH * sizeof(int32_t) + 4 * sizeof(int32_t));
@@ -751,6 +771,7 @@ static size_t sel_joint_bytes(int B) {
 static size_t sel_head_zero_bytes(int B, int H) {
   return (size_t)B * H * (SEL_BINS * sizeof(uint32_t) + sizeof(SjState) + 4 * sizeof(int32_t));
 }
+static size_t sel_slice_bytes(int B, int H, size_t P) { return (size_t)B * H * P * sizeof(unsigned long long); }
 
 extern "C" size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen) {
   if (B <= 0 || H <= 0) return 0;
@@ -758,7 +779,7 @@ extern "C" size_t cvllm_select_workspace_bytes(int B, int H, int max_seqlen) {
   if ((long)max_seqlen * H >= SJ_MIN) bytes += sel_joint_bytes(B);
   if (max_seqlen >= SH_MIN) {
     const size_t P = ((size_t)max_seqlen + SH_SLICE - 1) / SH_SLICE;
-    bytes += sel_head_zero_bytes(B, H) + (size_t)B * H * P * 2 * sizeof(int32_t);
+    bytes += sel_head_zero_bytes(B, H) + sel_slice_bytes(B, H, P);
   }
   return bytes;
 }
@@ -782,7 +803,8 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
   char* ph = pj + (joint_multi ? sel_joint_bytes(B) : 0);
   {
     // one memset for both multi-workgroup paths (their regions are adjacent)
-    const size_t zero = (joint_multi ? sel_joint_bytes(B) : 0) + (head_multi ? sel_head_zero_bytes(B, H) : 0);
+    const size_t zero = (joint_multi ? sel_joint_bytes(B) : 0) +
+                        (head_multi ? sel_head_zero_bytes(B, H) + sel_slice_bytes(B, H, (size_t)P) : 0);
     char* z0 = joint_multi ? pj : ph;
     if (zero && hipMemsetAsync(z0, 0, zero, st) != hipSuccess) return CVLLM_ERR_LAUNCH;
   }
@@ -808,12 +830,10 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
     uint32_t* gh2 = (uint32_t*)ph;
     SjState* st2 = (SjState*)(gh2 + (size_t)B * H * SEL_BINS);
     int* tickets2 = (int*)(st2 + (size_t)B * H);
-    int* slice_cnt = (int*)(ph + sel_head_zero_bytes(B, H));
+    unsigned long long* slice_cnt = (unsigned long long*)(ph + sel_head_zero_bytes(B, H));
     for (int pass = 0; pass < 3; ++pass)
       hipLaunchKernelGGL(sh_hist_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, gh2,
                          tickets2, H, pass, P);
-    hipLaunchKernelGGL(sh_count_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, slice_cnt,
-                       H, P);
     hipLaunchKernelGGL(sh_write_kernel, dim3(B * H * P), dim3(SJ_T), 0, st, scores, cu_seqlens_k, target, st2, slice_cnt,
                        kept_idx, H, P, max_seqlen);
   } else {
@@ -822,3 +842,10 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
   }
   return check_launch();
 }
+
+#ifdef CVLLM_SEL_TS
+extern "C" void cvllm_debug_select_stamps(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_sel_rt), sizeof(unsigned long long) * 8 * 64 * 8);
+}
+#endif
