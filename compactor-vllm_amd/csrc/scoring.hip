@@ -722,8 +722,9 @@ constexpr int LV2_T = 256;
 constexpr int LV2_W = LV2_T / 64;     // waves = wave tiles
 constexpr int LV2_NB = LV_FMAX / (32 * LV2_W);  // 32-row blocks per wave (4)
 constexpr int LV2_TILE = 32 * LV_LD;  // floats per wave tile (1568 >= 6 * 256: also holds a wave's partial Gram)
+constexpr int LV2_LP = 52;  // row pitch of L in LDS: 16-byte rows whose float4 stores by 16 lanes fall into distinct banks
 constexpr size_t LV2_SMEM =
-    (size_t)(LV2_W * LV2_TILE + LV_KD * LV_LD + LV_KD * LV_KD + LV_KD + LV2_W * LV_KMAX + LV_KMAX) * sizeof(float);
+    (size_t)(LV2_W * LV2_TILE + LV_KD * LV_LD + LV_KD * LV2_LP + LV_KD + LV2_W * LV_KMAX + LV_KMAX) * sizeof(float);
 template <typename T, int D>
 __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_t* __restrict__ key, int64_t s_n,
                                                                   int64_t s_h, const uint16_t* __restrict__ phi,
@@ -735,8 +736,8 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
   extern __shared__ __attribute__((aligned(16))) char lv_smem[];
   float* s_tiles = reinterpret_cast<float*>(lv_smem);   // [LV2_W][32][LV_LD]
   float* s_G = s_tiles + LV2_W * LV2_TILE;              // [48][LV_LD]  Gram, then W = L^-1
-  float* s_L = s_G + LV_KD * LV_LD;                     // [48][48]     L, strictly lower part (zero elsewhere)
-  float* s_Li = s_L + LV_KD * LV_KD;                    // [48]         1 / L[k][k]
+  float* s_L = s_G + LV_KD * LV_LD;                     // [48][LV2_LP] L, strictly lower part (zero elsewhere)
+  float* s_Li = s_L + LV_KD * LV2_LP;                   // [48]         1 / L[k][k]
   float* s_part = s_Li + LV_KD;                         // [LV2_W][64]  per-wave column sums
   float* s_mu = s_part + LV2_W * LV_KMAX;               // [64]
   uint16_t(*s_phiT)[D + 8] = reinterpret_cast<uint16_t(*)[D + 8]>(lv_smem);  // aliases the tiles until pf is loaded
@@ -894,21 +895,35 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
       float dinv_mine = 0.f;
 #pragma unroll
       for (int cc = 0; cc < LV_KD; ++cc) a[cc] = s_G[rown * LV_LD + cc];
-#pragma unroll
+#pragma clang loop unroll(full)
       for (int j = 0; j < LV_KD; ++j) {
         const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j));
         const float dinv = __builtin_amdgcn_rsqf(piv);  // 1 / L[j][j]
         a[j] *= dinv;                                    // lane j: sqrt(piv) = L[j][j]; lanes i > j: L[i][j]
         dinv_mine = (lane == j) ? dinv : dinv_mine;
+        // A[i][k] -= L[i][j] L[k][j] (meaningful for i >= k), eight columns at a time: eight v_readlane into eight
+        // SGPRs, then eight FMAs.  Left to itself hipcc funnels every broadcast through ONE SGPR - readlane, two wait
+        // states, FMA, 1 176 times: 7 of the 15.7 us this phase took (profiles/r02_scoring_phase_stamps.txt)
+#pragma clang loop unroll(full)
+        for (int k0 = j + 1; k0 < LV_KD; k0 += 8) {
+          float lk[8];
 #pragma unroll
-        for (int kk = j + 1; kk < LV_KD; ++kk) {
-          const float lkj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), kk));
-          a[kk] = fmaf(-a[j], lkj, a[kk]);  // A[i][k] -= L[i][j] L[k][j]   (meaningful for i >= k)
+          for (int u = 0; u < 8; ++u)
+            if (k0 + u < LV_KD)
+              lk[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), k0 + u));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k0 + u < LV_KD) a[k0 + u] = fmaf(-a[j], lk[u], a[k0 + u]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (lane < LV_KD) {
 #pragma unroll
-        for (int cc = 0; cc < LV_KD; ++cc) s_L[lane * LV_KD + cc] = cc < lane ? a[cc] : 0.f;
+        for (int c4 = 0; c4 < LV_KD / 4; ++c4)  // (scalar stores at a pitch of 48 floats: 16-way bank conflicts)
+          *reinterpret_cast<float4*>(s_L + lane * LV2_LP + 4 * c4) =
+              make_float4(4 * c4 < lane ? a[4 * c4] : 0.f, 4 * c4 + 1 < lane ? a[4 * c4 + 1] : 0.f,
+                          4 * c4 + 2 < lane ? a[4 * c4 + 2] : 0.f, 4 * c4 + 3 < lane ? a[4 * c4 + 3] : 0.f);
         s_Li[lane] = dinv_mine;
       }
     }
@@ -920,7 +935,7 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
         float t = (kk == rown) ? 1.f : 0.f;
 #pragma unroll
         for (int m4 = 0; m4 < (kk + 3) / 4; ++m4) {  // entries m >= kk of row kk are zero: no masking needed
-          const float4 l4 = *reinterpret_cast<const float4*>(s_L + kk * LV_KD + 4 * m4);
+          const float4 l4 = *reinterpret_cast<const float4*>(s_L + kk * LV2_LP + 4 * m4);
           t = fmaf(-l4.x, w[4 * m4], t);
           if (4 * m4 + 1 < kk) t = fmaf(-l4.y, w[4 * m4 + 1], t);
           if (4 * m4 + 2 < kk) t = fmaf(-l4.z, w[4 * m4 + 2], t);
@@ -928,7 +943,9 @@ __global__ __launch_bounds__(LV2_T, 2) void leverage_fused2_kernel(const uint16_
         }
         w[kk] = t * s_Li[kk];
         // anchor: w is only stored after the loop, so hipcc otherwise sinks the whole FMA chain below the 294 float4
-        // loads of the 48 steps and spills every loaded value
+        // loads of the 48 steps and spills every loaded value.  (Requesting row kk + 1 before row kk's chain: this
+        // phase 13.2 -> 11.3 us, but 28 registers spilled around it - the sketch stays in 128 accumulators - and the
+        // solve phase 11.5 -> 17.5 us: not kept.)
         asm volatile("" : "+v"(w[kk]));
         __builtin_amdgcn_sched_barrier(0);
       }
