@@ -439,6 +439,21 @@ __host__ __device__ constexpr int p4_mb(int k) {
 }
 static_assert(p4_mb(0) == 0 && p4_mb(24) == 112, "exp micro-op placement");
 static_assert(p4_mb(16) >= 4 + 7 * 7 + 7, "P of keys 0-15 must be complete before the first PV MFMA");
+// -DCVLLM_PF_TS (debug builds of tools/dbg only): s_memrealtime at the phase boundaries of every workgroup
+#ifdef CVLLM_PF_TS
+__device__ unsigned long long g_pf_rt[8192 * 8];  // [workgroup][4 x s_memrealtime (100 MHz) | 4 x s_memtime (shader clock)]
+#define PF_RT(i)                                                                                              \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                              \
+      g_pf_rt[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                                       \
+      g_pf_rt[blockIdx.x * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime();                                       \
+    }                                                                                                         \
+  } while (0)
+#else
+#define PF_RT(i) \
+  do {           \
+  } while (0)
+#endif
 constexpr int P4_THREADS = 256;
 constexpr int P4_SMEM = 3 * PF_KTILE + 3 * PF_VTILE;  // K and V triple-buffered: 113,664 B
 static_assert(P4_SMEM >= 4 * 64 * PF_OSTRIDE, "O staging image must fit");
@@ -466,6 +481,7 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   const int La = cu[b + 1] - s0;
   const int nqt = (La + BM - 1) / BM;
   if (tile_rev >= nqt) return;
+  PF_RT(0);
   const int qt = nqt - 1 - tile_rev;  // heaviest tiles first
   const int m0 = qt * BM;
   const int HQ = HKV * G;
@@ -877,6 +893,7 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   // Pairs of tiles, then an odd last one: with the second body under an `if` inside the loop, hipcc's wait-count
   // pass merges "set 0 loaded last" into the loop header and drains vmcnt to 0 in front of every LDS write of set 0.
   int cur = 0;  // t % 3
+  PF_RT(1);
   int t = 0;
   for (; t + 1 < ntiles; t += 2) {
     tile_body(t, cur, std::integral_constant<int, 0>{});
@@ -885,6 +902,7 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     cur = cur == 2 ? 0 : cur + 1;
   }
   if (t < ntiles) tile_body(t, cur, std::integral_constant<int, 0>{});
+  PF_RT(2);
 
   // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ---------------------------
   char* ob = smem + wave * (64 * PF_OSTRIDE);
@@ -916,6 +934,7 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       *reinterpret_cast<uint4*>(out + ((size_t)(s0 + gtok) * HQ + ghead) * D + ch * 8) = val;
     }
   }
+  PF_RT(3);
 }
 
 // CVLLM_PREFILL=8wave selects the 8-wave kernel for every shape (A/B measurements and the cross-check test)
@@ -1008,3 +1027,10 @@ extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, i
 #undef PF_D
   return CVLLM_ERR_SHAPE;
 }
+
+#ifdef CVLLM_PF_TS
+extern "C" void cvllm_debug_prefill_stamps(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_pf_rt), sizeof(unsigned long long) * 8192 * 8);
+}
+#endif
