@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256, CM_OCC) void chunk_mass_kernel(const uint16_t*
   // the fragments straight from global memory is 32-byte pieces of rows 8 KB apart: 117 us for 336 MB.)
   constexpr int RPI = 64 / CH;   // rows per load instruction
   constexpr int NI = 32 / RPI;   // load instructions per 32-row block
-  uint4 qn[NI];  // (two blocks in flight, block loop unrolled in pairs: 228-254 registers spilled - not kept)
+  uint4 qn[NI];  // (two blocks in flight, block loop unrolled in pairs: 228-254 registers spilled - not kept; four chunks
+                 // per workgroup with the next chunk's K tile / first Q block requested ahead: 110-149 spilled - not kept)
   char* s_qw = s_q + wave * (32 * 256);
   const int lrow = lane / CH, lch = lane % CH;
   auto load_q = [&](int qb) __attribute__((always_inline)) {
