@@ -127,9 +127,16 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
         replay = graph.replay
     else:  # --no-graph (the rocprofv3 --pmc passes): the same launches issued eagerly
         replay = one_pass
-    replay()
-    torch.cuda.synchronize()
+    # warm replays for ~50 ms before the timed ones, so that the clocks have settled under this load
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    replay()
+    e1.record()
+    torch.cuda.synchronize()
+    first = max(e0.elapsed_time(e1) * 1e-3, 1e-5)
+    for _ in range(min(200, int(0.05 / first) + 1)):
+        replay()
+    rounds = max(rounds, min(50, int(0.02 / first) + 1))
     e0.record()
     for _ in range(rounds):
         replay()
@@ -154,7 +161,8 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
             "timing": f"one HIP event pair on the launch stream around {rounds} queued "
                       + ("replays of a HIP graph holding" if use_graph else "eager passes of")
                       + f" the product's decode-attention call of all {nl} layers back to back (each on its own cache), "
-                      f"divided by {rounds * nl}; includes the inter-launch dispatch gap"}
+                      f"divided by {rounds * nl}; includes the inter-launch dispatch gap; ~50 ms of untimed replays "
+                      f"first (clocks settled: a cold leg of 5 replays read 4 % / 15 % lower at 1 / 4 sequences)"}
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
@@ -164,7 +172,8 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 def roofline_prefill_attn(model, ctx, rounds=3):
     """Second roofline object: the prefill attention kernel (MFMA-bound) at the workload's context length on
     synthetic q/k/v of the model's head shape with an empty cache; causal FLOPs = 4 * S^2 * D * HQ / 2 per launch,
-    timed with events on the current stream (the stream the kernel is launched on) around `rounds` launches."""
+    timed with events on the current stream (the stream the kernel is launched on) around `rounds` (or more) launches
+    after a warm-up long enough for the clock to settle."""
     from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
 
     cfg, dev = model.cfg, model.dev
@@ -180,8 +189,17 @@ def roofline_prefill_attn(model, ctx, rounds=3):
         return causal_sparse_varlen_with_cache(q, k, v, a.k_cache, a.v_cache, lens, a.page_table, bm, cu, ctx, 0,
                                                cfg.kv_heads, a.page_size)
 
-    run()
+    # Warm until ~50 ms of this kernel have run: the chip's clock takes that long to settle under a matrix-pipe load (a
+    # 16 K launch timed after one warm launch reads 2.30 ms, 1.98 ms once settled; profiles/r02_prefill_workgroup_stamps.txt)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run()
+    e1.record()
+    torch.cuda.synchronize()
+    first = max(e0.elapsed_time(e1) * 1e-3, 1e-5)
+    for _ in range(min(40, int(0.05 / first) + 1)):
+        run()
+    rounds = max(rounds, min(10, int(0.03 / first) + 1))
     e0.record()
     for _ in range(rounds):
         run()

@@ -87,7 +87,10 @@ def bench_prefill(args):
         bm = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
         cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L
         fn = lambda: causal_sparse_varlen_with_cache(q, k, v, kc, kc, lens, pt, bm, cu, L, 0, HKV, PS)
-        us = time_fn(fn, iters=5, warmup=2)
+        # warm until ~40 ms of this kernel have run: with 2 warm launches a 16 K kernel (2 ms) was still timed on a ramping
+        # clock (2.30 ms against 2.03 steady, profiles/r02_prefill_workgroup_stamps.txt)
+        warm = max(2, min(40, int(40e-3 / (4e-9 * 2 * L * L / 2 * B / 1e3 + 1e-4))))
+        us = time_fn(fn, iters=max(5, warm // 2), warmup=warm)
         flops = 4 * D * HQ * B * (L * (L + 1) / 2)
         print(f"prefill B={B} L={L}: {us / 1e3:9.3f} ms  {flops / us / 1e6:8.1f} TFLOP/s (causal flops)", flush=True)
 
