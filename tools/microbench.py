@@ -65,7 +65,7 @@ def bench_decode(args):
             with torch.cuda.graph(g):
                 for kc, vc in caches:
                     out = dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS)
-            us = time_fn(g.replay, iters=20, warmup=3) / layers
+            us = time_fn(g.replay, iters=50, warmup=max(3, int(40e3 / (25.0 * layers)))) / layers  # ~40 ms of warm replays: settled clocks
             print(f"decode variant={variant} B={B} L={L} splits={S:3d} layers={layers}: {us:8.2f} us/(stage1+merge)  "
                   f"{bytes_alg / us / 1e6:7.3f} TB/s algorithmic", flush=True)
 
