@@ -145,7 +145,7 @@ def bench_scoring(args):
         ("store_all", store_all),
     ]
     for name, fn in items:
-        us = time_fn(fn, iters=10, warmup=3)
+        us = time_fn(fn, iters=50, warmup=300)  # ~30 ms of warm calls: settled clocks (3 warm calls read 5-15 % higher)
         print(f"scoring B={B} L={L}: {name:42s} {us:9.1f} us", flush=True)
 
 
