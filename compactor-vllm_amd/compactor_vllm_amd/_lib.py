@@ -29,6 +29,7 @@ SIGNATURES = {
     "cvllm_decode_append_attn": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I,
                                       _I, _F, _I, _I, _I, _P]),
     "cvllm_decode_merge_status": (_I, [_P, _P]),
+    "cvllm_decode_set_merge_mode": (_I, [_I]),
     "cvllm_num_splits": (_I, [_I, _I, _I, _I]),
     "cvllm_store_decode_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvllm_store_all_kv": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -40,11 +41,12 @@ SIGNATURES = {
     "cvllm_leverage_workspace_bytes": (_Z, [_I, _I, _I]),
     "cvllm_leverage_scores": (_I, [_P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _Z, _P]),
     "cvllm_snapkv_workspace_bytes": (_Z, [_I, _I, _I, _I]),
-    "cvllm_snapkv_scores": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _Z, _P]),
-    "cvllm_snapkv_scores_wb": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _Z, _P]),
+    "cvllm_snapkv_scores": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P, _Z, _P]),
+    "cvllm_snapkv_scores_wb": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P, _Z, _P]),
     "cvllm_zscore_windowed": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "cvllm_select_workspace_bytes": (_Z, [_I, _I, _I]),
     "cvllm_select_topk": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "cvllm_select_status": (_I, [_P]),
     "cvllm_compact_store": (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                                  _I, _I, _P]),
     "cvllm_compact_cache_inplace": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -41,25 +41,42 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return buf
 
 
+_MERGE_MODES = {"default": 0, "two-kernel": 1, "in-launch": 2}
+
+
+def set_merge_mode(mode: str) -> str:
+    """Process-wide choice of the split merge for grids that fit the chip: "two-kernel" (fp32 partials +
+    decode_stage2_kernel; the default), "in-launch" (one launch, needs every workgroup co-resident: poll `merge_status`),
+    "default" (the environment's CVLLM_DECODE_MERGE, else two-kernel).  Returns the previous setting.  A captured graph
+    keeps the mode it was captured with."""
+    prev = int(_lib.lib().cvllm_decode_set_merge_mode(_MERGE_MODES[mode]))
+    return {v: k for k, v in _MERGE_MODES.items()}[prev]
+
+
 def merge_status(device: torch.device | None = None) -> int:
-    """Health check of the in-launch split merge for the current stream's workspace (synchronises the stream):
-    0 = fine; 1 = some call gave up waiting for a sibling split (its output rows hold NaN) - the workspace is then
-    re-zeroed here so that later calls start clean."""
+    """Health check of the in-launch split merge (only used with CVLLM_DECODE_MERGE=in-launch) over EVERY live decode
+    workspace of the device - graphs launch on their capture stream's workspace, eager calls on the current stream's, so
+    looking at one stream's buffer would miss the others.  Synchronises the device.  0 = fine; 1 = some call gave up
+    waiting for a sibling split (its output rows hold NaN) - the affected workspaces are re-zeroed here so that later
+    calls start clean."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _workspaces.get(key)
-    if buf is None:
+    bufs = [buf for (dev_index, _), buf in _workspaces.items() if dev_index == device.index]
+    if not bufs:
         return 0
-    st = int(_lib.lib().cvllm_decode_merge_status(buf.data_ptr(), _lib.stream()))
-    if st < 0:
-        _lib.check(st, "cvllm_decode_merge_status")
-    if st:
-        buf.zero_()
-    return st
+    torch.cuda.synchronize(device)
+    bad = 0
+    for buf in bufs:
+        st = int(_lib.lib().cvllm_decode_merge_status(buf.data_ptr(), _lib.stream()))
+        if st < 0:
+            _lib.check(st, "cvllm_decode_merge_status")
+        if st:
+            buf.zero_()
+            bad = 1
+    return bad
 
 
-# MI355X: the in-launch merge needs the whole grid resident (one ring workgroup per CU), so the split count is the
-# largest that keeps batch * kv-heads * splits within the chip's CUs
+# MI355X: one ring workgroup per CU streams at the chip rate, so the split count is the largest that keeps
+# batch * kv-heads * splits within the chip's CUs
 @functools.lru_cache(maxsize=None)
 def _cus(device_index: int) -> int:
     global _TARGET_WORKGROUPS

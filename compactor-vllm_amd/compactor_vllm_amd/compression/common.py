@@ -86,6 +86,16 @@ def select_retained(
     return kept, new_lens
 
 
+def select_status() -> int:
+    """Health check of the selection kernels on the current device (synchronises the current stream): 0 = fine,
+    1 = a look-back wait of the per-head ordered write timed out since the last check (`cvllm_select_status`; the word
+    is cleared).  The engine calls it once per prefill, after the store stream has been joined, and raises."""
+    st = int(_lib.lib().cvllm_select_status(_lib.stream()))
+    if st < 0:
+        _lib.check(st, "cvllm_select_status")
+    return st
+
+
 def extract_and_store_top_kv(
     scores: torch.Tensor,
     cu_seqlens_k: torch.Tensor,

@@ -69,15 +69,20 @@ def query_aware_key_scores(
     accum_blending: float = None,
     normalize: bool = False,
     max_seqlen_k: int = None,
+    pool_tile: int = 128,
 ) -> Optional[torch.Tensor]:
     """s_j = sum over the last `w` queries x G heads of softmax_row(q k^T / sqrt D) restricted to keys
-    [0, L-w); trailing 5-tap mean clipped at 128-key tiles (reference BLOCK_K pinned to 128, SURVEY P3);
+    [0, L-w); trailing 5-tap mean clipped at the start of the key's `pool_tile`-wide block (counted from the sequence
+    start): `pool_tile` in {32, 64, 128} is the BLOCK_K the reference's autotuner picked for its
+    `_scores_from_logits_kernel` (snapkv.py:160-168, 253-262) - the pooled values depend on it, so a caller that must
+    match a given reference box passes that box's outcome (default 128; extension argument);
     last w keys <- +inf.  fp32 [N_k, Hk].  `w` is an int (the engine passes 32) or a [B] int32 tensor of per-sequence
     windows (one host sync for its maximum, like the reference's `w.max().item()`).  normalize=True z-scores every
     sequence's scored rows [0, L-w) over all heads (biased variance, eps 1e-12 inside the square root; reference
     :279-329).  `max_seqlen_k` avoids a host sync; when omitted it is read from cu_seqlens_k.  Sequences with L <= w
     come back all +inf (reference: uninitialised)."""
     assert q.stride(-1) == 1 and k.stride(-1) == 1, "last dim must be contiguous"
+    assert pool_tile in (32, 64, 128), "pool_tile must be one of the reference's BLOCK_K configurations"
     _lib.require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
     w_b = None
     if not isinstance(w, int):
@@ -104,7 +109,8 @@ def query_aware_key_scores(
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=q.device)
     st = L.cvllm_snapkv_scores_wb(
         q.data_ptr(), k.data_ptr(), q.stride(0), k.stride(0), k.stride(1), out.data_ptr(), cq.data_ptr(), ck.data_ptr(),
-        _lib.ptr(w_b), B, Hq, Hk, D, int(w), float(sm_scale), 5, int(max_seqlen_k), _lib.dtype_code(q.dtype),
+        _lib.ptr(w_b), B, Hq, Hk, D, int(w), float(sm_scale), 5, int(pool_tile), int(max_seqlen_k),
+        _lib.dtype_code(q.dtype),
         ws.data_ptr(), ws_bytes, _lib.stream(),
     )
     _lib.check(st, "cvllm_snapkv_scores_wb")

@@ -72,6 +72,10 @@ class ModelRunner:
                             self.device, seed)
         self.num_kv_heads = int(hf.num_key_value_heads)
         self.captured_graphs: Dict[Tuple[int, int], _GraphSlot] = {}
+        # ONE capture stream for every bucket: per-stream scratch (the decode workspace) is then shared by all graphs
+        # and its key can never be recycled.  Replays must stay on one stream at a time (they do: the engine is
+        # single-threaded and replays on the current stream).
+        self._capture_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.last_scheduler: Optional[Scheduler] = None
 
     # ------------------------------------------------------------------------------------------------ prefill
@@ -132,6 +136,29 @@ class ModelRunner:
         if self.store_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.store_stream)
 
+    def _check_prefill_health(self) -> None:
+        """Once per prefill wave, after the store stream has been joined and before the per-head lengths are trusted:
+        the selection kernels' sticky error word (a bounded look-back wait that expired, cvllm_select_status).  The
+        page reclamation that follows synchronises anyway (it reads the lengths on the host)."""
+        if not self.on_gpu:
+            return
+        from ..compression.common import select_status
+
+        if select_status() != 0:
+            raise RuntimeError("KV selection failed: a slice of the ordered write timed out waiting for the slices "
+                               "before it (cvllm_select_status); the retained sets of this prefill are incomplete")
+
+    def _check_decode_health(self) -> None:
+        """Once per generate call: the in-launch split merge's error word of every decode workspace (only ever raised
+        with CVLLM_DECODE_MERGE=in-launch; the default two-kernel merge has no wait that can expire)."""
+        if not self.on_gpu:
+            return
+        from ..attention.sparse_decode_kernel import merge_status
+
+        if merge_status(self.device) != 0:
+            raise RuntimeError("decode attention: an in-launch split merge timed out (cvllm_decode_merge_status); "
+                               "tokens generated by this call are invalid")
+
     # ------------------------------------------------------------------------------------------------ generate
     @torch.inference_mode()
     def generate(self, all_sequences: List[Sequence], batch_compression_params: Optional[BatchCompressionParams] = None):
@@ -161,6 +188,8 @@ class ModelRunner:
                     pending_out.append((tokens, ids))
                     # H2: the per-head lengths are written on the store stream
                     self._join_store_stream()
+                    if args.do_compression:
+                        self._check_prefill_health()
                     self.kv_manager.reclaim_pages(ids, args.max_new_tokens.tolist())
                     occupancy = int((len(batch) + len(ids)) * 0.66) if sched.any_pending_sequences() else -1
                     batch.update(rows, tokens, args.context_lens.to(torch.int64), max_ctx, args.seq_ids, temps, occupancy)
@@ -180,6 +209,7 @@ class ModelRunner:
                 sched.update_sequences(out.output_tokens.tolist(), out.output_seq_ids.tolist())
         finally:
             sched.close()
+        self._check_decode_health()
         return all_sequences
 
     # ------------------------------------------------------------------------------------------------ decode loop
@@ -248,7 +278,7 @@ class ModelRunner:
         slot.positions = torch.zeros(bs, dtype=torch.int64, device=dev)
         slot.batch_mapping = torch.full((bs,), RESERVED_BATCH, dtype=torch.int32, device=dev)
         set_context(is_prefill=False, do_compression=False, batch_mapping=slot.batch_mapping, decode_len_hint=ctx_bucket)
-        side = torch.cuda.Stream(device=dev)
+        side = self._capture_stream
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up on the capture stream: lazy allocations (per-stream workspaces) happen here

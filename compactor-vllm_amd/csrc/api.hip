@@ -1,7 +1,7 @@
 // Version / error strings of the C ABI.
 #include "common.h"
 
-extern "C" int cvllm_version(void) { return 100; }  // 0.1.0
+extern "C" int cvllm_version(void) { return 110; }  // 0.1.1 (round 3: cvllm_select_status, pool_tile)
 
 extern "C" const char* cvllm_error_string(int status) {
   switch (status) {

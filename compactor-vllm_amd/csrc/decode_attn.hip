@@ -1050,12 +1050,18 @@ static int device_cus() {
   return cus[dev];
 }
 
-// CVLLM_DECODE_MERGE=two-kernel forces the separate merge kernel (A/B measurements, tests of that path)
+// Which split merge runs when the grid fits the chip.  Default: the two-kernel path (fp32 partials +
+// decode_stage2_kernel) - it needs no co-residency, cannot time out and measures the same (profiles/r02_decode_kernel_
+// durations.txt: 22.57 us in-launch against 18.19 + 4.74 us; r03 A/B inside the engine's graph in profiles/).
+// CVLLM_DECODE_MERGE=in-launch opts into the one-launch form (callers must then poll cvllm_decode_merge_status);
+// CVLLM_DECODE_MERGE=two-kernel states the default explicitly.
+static int g_merge_override = 0;  // cvllm_decode_set_merge_mode: 0 = environment / default, 1 = two-kernel, 2 = in-launch
 static bool merge_in_launch_allowed() {
+  if (g_merge_override) return g_merge_override == 2;
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CVLLM_DECODE_MERGE");
-    v = (e && (e[0] == 't' || e[0] == '2')) ? 0 : 1;
+    v = (e && (e[0] == 'i' || e[0] == '1')) ? 1 : 0;
   }
   return v == 1;
 }
@@ -1237,6 +1243,14 @@ extern "C" int cvllm_decode_append_attn(const void* q, const void* key, const vo
   a.B = B; a.HKV = HKV; a.PS = page_size; a.NLP = n_logical_pages_max; a.S = n_splits; a.lens_by_row = 1;
   a.reserved = reserved_batch; a.scale = sm_scale; a.st = (hipStream_t)stream;
   return decode_common(a, HQ, D, dtype, workspace_bytes);
+}
+
+// Process-wide choice of the split merge for grids that fit the chip (host state, not a launch): 0 = what the
+// environment says (CVLLM_DECODE_MERGE, default two-kernel), 1 = two-kernel, 2 = in-launch.  Returns the previous value.
+extern "C" int cvllm_decode_set_merge_mode(int mode) {
+  const int prev = g_merge_override;
+  if (mode >= 0 && mode <= 2) g_merge_override = mode;
+  return prev;
 }
 
 // Status of the in-launch split merge of the calls that used `workspace` so far: 0 = fine, 1 = a merging workgroup

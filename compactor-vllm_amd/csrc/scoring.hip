@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256, 2) void snapkv_kernel(const uint16_t* __restri
                                                         const int* __restrict__ cu_q, const int* __restrict__ cu_k,
                                                         int B, int HKV, int w_max, const int* __restrict__ w_b,
                                                         int ntile_max, float scale_log2e,
-                                                        int pool) {
+                                                        int pool, int pool_tile) {
   constexpr int KS = D / 16;
   constexpr int CH = D / 8;
   constexpr int KPT = SK_TILE * CH / 256;  // 16-byte chunks of a K tile per thread
@@ -1241,13 +1241,14 @@ __global__ __launch_bounds__(256, 2) void snapkv_kernel(const uint16_t* __restri
     }
   } else {
     // epilogue, once per workgroup: the four waves' column sums, then the causal avg-pool, kernel `pool`, clipped
-    // at the TILE start (snapkv.py:253-262 with BLOCK_K = 128)
+    // at the start of the key's pool_tile-wide block counted from the sequence start (snapkv.py:253-262: the reference's
+    // autotuned BLOCK_K in {32, 64, 128}; pool_tile divides SK_TILE, so a block never straddles a workgroup's tiles)
     const int nk = min(keff - tile0 * SK_TILE, (tile1 - tile0) * SK_TILE);
     constexpr int WS = SK_TPW * SK_TILE;
     for (int i = tid; i < nk; i += 256) s_col[i] = s_col[i] + s_col[WS + i] + s_col[2 * WS + i] + s_col[3 * WS + i];
     __syncthreads();
     for (int i = tid; i < nk; i += 256) {
-      const int j = i % SK_TILE;
+      const int j = i & (pool_tile - 1);
       const int lo = max(0, j - (pool - 1));
       float t = 0.f;
       for (int jj = lo; jj <= j; ++jj) t += s_col[i - j + jj];
@@ -1493,7 +1494,7 @@ extern "C" size_t cvllm_snapkv_workspace_bytes(int B, int HKV, int w, int max_se
 template <typename T, int D>
 static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h, float* scores,
                     float* part, const int* cu_q, const int* cu_k, int B, int HKV, int w, const int* w_b, int ntile,
-                    float scale, int pool, hipStream_t st) {
+                    float scale, int pool, int pool_tile, hipStream_t st) {
   const float c = scale * 1.4426950408889634f;
   dim3 grid(B * ((ntile + SK_TPW - 1) / SK_TPW) * HKV), block(256);
   float* lse = part + (size_t)B * HKV * ntile * (SK_MAXQB * 32) * 2;
@@ -1505,11 +1506,11 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
     set_dyn_lds_once(k1, (int)SK_SMEM);                                                                               \
     set_dyn_lds_once(k2, (int)SK_SMEM);                                                                               \
     hipLaunchKernelGGL(k1, grid, block, SK_SMEM, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, sk_n, sk_h,        \
-                       scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool);                  \
+                       scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool, pool_tile);       \
     hipLaunchKernelGGL(snapkv_lse_kernel, dim3(B* HKV*(SK_MAXQB * 32) / (SK_LSE_T / 64)), dim3(SK_LSE_T), 0, st,      \
                        (const float*)part, lse, cu_k, HKV, w, w_b, G_, ntile);                                        \
     hipLaunchKernelGGL(k2, grid, block, SK_SMEM, st, (const uint16_t*)q, (const uint16_t*)k, sq_n, sk_n, sk_h,        \
-                       scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool);                  \
+                       scores, part, (const float*)lse, cu_q, cu_k, B, HKV, w, w_b, ntile, c, pool, pool_tile);       \
   }
 #define SNAP(G_)                                                                                                      \
   {                                                                                                                   \
@@ -1530,10 +1531,12 @@ static int snapkv_g(int G, const void* q, const void* k, int64_t sq_n, int64_t s
 extern "C" int cvllm_snapkv_scores_wb(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                                       float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                                       const int32_t* window_b, int B, int HQ, int HKV, int D, int w, float sm_scale,
-                                      int pool, int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
-                                      cvllm_stream_t stream) {
+                                      int pool, int pool_tile, int max_seqlen_k, int dtype, void* workspace,
+                                      size_t workspace_bytes, cvllm_stream_t stream) {
   if (!q || !k || !scores || !cu_seqlens_q || !cu_seqlens_k) return CVLLM_ERR_ARG;
   if (B <= 0 || HQ <= 0 || HKV <= 0 || max_seqlen_k <= 0 || pool <= 0) return CVLLM_ERR_ARG;
+  if (pool_tile == 0) pool_tile = SK_TILE;
+  if (pool_tile != 32 && pool_tile != 64 && pool_tile != 128) return CVLLM_ERR_SHAPE;  // the reference's three configs
   if (HQ % HKV != 0) return CVLLM_ERR_SHAPE;
   const int G = HQ / HKV;
   if (w <= 0 || w * G > SK_MAXQB * 32) return CVLLM_ERR_SHAPE;
@@ -1544,7 +1547,7 @@ extern "C" int cvllm_snapkv_scores_wb(const void* q, const void* k, int64_t sq_n
   float* part = (float*)workspace;
 #define SNAPD(T_, D_)                                                                                              \
   return snapkv_g<T_, D_>(G, q, k, sq_n, sk_n, sk_h, scores, part, cu_seqlens_q, cu_seqlens_k, B, HKV, w, window_b, \
-                          ntile, sm_scale, pool, st)
+                          ntile, sm_scale, pool, pool_tile, st)
   if (dtype == CVLLM_F16 && D == 128) SNAPD(F16, 128);
   if (dtype == CVLLM_F16 && D == 64) SNAPD(F16, 64);
   if (dtype == CVLLM_BF16 && D == 128) SNAPD(BF16, 128);
@@ -1555,10 +1558,11 @@ extern "C" int cvllm_snapkv_scores_wb(const void* q, const void* k, int64_t sq_n
 
 extern "C" int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                                    float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int B,
-                                   int HQ, int HKV, int D, int w, float sm_scale, int pool, int max_seqlen_k,
-                                   int dtype, void* workspace, size_t workspace_bytes, cvllm_stream_t stream) {
+                                   int HQ, int HKV, int D, int w, float sm_scale, int pool, int pool_tile,
+                                   int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
+                                   cvllm_stream_t stream) {
   return cvllm_snapkv_scores_wb(q, k, sq_n, sk_n, sk_h, scores, cu_seqlens_q, cu_seqlens_k, nullptr, B, HQ, HKV, D, w,
-                                sm_scale, pool, max_seqlen_k, dtype, workspace, workspace_bytes, stream);
+                                sm_scale, pool, pool_tile, max_seqlen_k, dtype, workspace, workspace_bytes, stream);
 }
 
 #ifdef CVLLM_SC_TS

@@ -670,6 +670,14 @@ __global__ __launch_bounds__(SJ_T) void sh_hist_kernel(const float* __restrict__
 // block ids, so the in-order dispatcher has started every one of them before this one - the wait cannot deadlock; it is
 // bounded all the same) and places its kept token indices behind theirs: the list stays ascending.
 constexpr unsigned long long SH_FLAG = 1ull << 63;
+// Sticky error word of the selection kernels (per device): bit 0 = a look-back wait timed out.  Read and cleared by
+// cvllm_select_status; the product library never traps.
+__device__ unsigned g_select_err = 0;
+#ifdef CVLLM_SEL_WITHHOLD  // tools/dbg test build only: slice 0 of every column withholds its word, short timeout
+constexpr unsigned long long SH_WAIT_TICKS = 200000ull;  // 2 ms at 100 MHz
+#else
+constexpr unsigned long long SH_WAIT_TICKS = 50000000ull;  // 0.5 s at 100 MHz
+#endif
 static_assert(SH_SLICE == SJ_T * 8, "eight keys of a slice per thread");
 __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict__ scores, const int* __restrict__ cu,
                                                         const int* __restrict__ target, const SjState* __restrict__ st,
@@ -710,7 +718,11 @@ __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict_
   const int gt_before_me = block_excl_scan_cnt_t<SJ_T>(gt, s_wsum, tg);
   const int eq_before_me = block_excl_scan_cnt_t<SJ_T>(eq, s_wsum, te);
   unsigned long long* col = slice_cnt + (size_t)bh * P;
+#ifdef CVLLM_SEL_WITHHOLD
+  if (tid == 0 && p != 0)
+#else
   if (tid == 0)
+#endif
     __hip_atomic_store(&col[p], SH_FLAG | ((unsigned long long)(uint32_t)tg << 31) | (unsigned long long)(uint32_t)te,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // look-back over the slices before this one (P <= 64: one thread each), then a serial fold in slice order by thread 0
@@ -720,8 +732,15 @@ __global__ __launch_bounds__(SJ_T) void sh_write_kernel(const float* __restrict_
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     do {
       wv = __hip_atomic_load(&col[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while (!(wv & SH_FLAG) && __builtin_amdgcn_s_memrealtime() - t0 < 50000000ull);  // 0.5 s at 100 MHz
-    if (!(wv & SH_FLAG)) __builtin_trap();  // cannot happen with in-order dispatch; never continue with a wrong count
+    } while (!(wv & SH_FLAG) && __builtin_amdgcn_s_memrealtime() - t0 < SH_WAIT_TICKS);
+    if (!(wv & SH_FLAG)) {
+      // A slice before this one never published (dispatch order is not a contract; a preempted or masked-off workgroup
+      // could do it).  Never trap and never spin on: raise the sticky error word (cvllm_select_status) and carry on with
+      // that slice counted as empty - every index written below is then a valid token and lies inside the list (the
+      // offsets can only be too SMALL), entries left unwritten are clamped by the consumers (store_kv.hip).
+      __hip_atomic_fetch_or(&g_select_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wv = SH_FLAG;
+    }
     s_prev[tid] = wv;
   }
   __syncthreads();
@@ -841,6 +860,24 @@ extern "C" int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_
                        max_seqlen);
   }
   return check_launch();
+}
+
+// Health check of the selection kernels on the current device: 0 = fine, 1 = a look-back wait of the per-head ordered
+// write timed out since the last check (the kept lists of that call are incomplete; the word is cleared here).
+// Synchronises the stream - for tests and for the engine's one check per prefill, not part of the data path.
+extern "C" int cvllm_select_status(cvllm_stream_t stream) {
+  unsigned w = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyFromSymbolAsync(&w, HIP_SYMBOL(cvllm::g_select_err), sizeof(w), 0, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return CVLLM_ERR_LAUNCH;
+  if (w) {
+    const unsigned z = 0;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(cvllm::g_select_err), &z, sizeof(z), 0, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return CVLLM_ERR_LAUNCH;
+  }
+  return (int)(w & 1u);
 }
 
 #ifdef CVLLM_SEL_TS

@@ -99,8 +99,11 @@ __global__ __launch_bounds__(256) void compact_store_kernel(
   const int* list = kept_idx + (size_t)bh * max_seqlen;
   const int* pt = page_table + ((size_t)bmap[b] * H + h) * NLP;
   const int n0 = cu[b];
+  const int Lb1 = cu[b + 1] - n0 - 1;
   for (int j = tile * RPB + rl; j < cnt; j += tiles_per_bh * RPB) {
-    const int n = n0 + list[j];
+    // clamped into the sequence: a kept list left incomplete by a failed selection (cvllm_select_status) must never
+    // turn into an out-of-range row
+    const int n = n0 + max(0, min(list[j], Lb1));
     const int pos = L0 + j;
     const int pg = pt[pos / PS];
     const size_t dst = ((size_t)pg * PS + pos % PS) * D + dl * 8;
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256) void compact_inplace_kernel(
   const int b = bh / H, h = bh % H;
   const int d0 = dst_base[bh], s0 = src_base[bh];
   const int cnt = new_lens[bh] - d0;
+  const int tok_max = NLP * PS - 1 - s0;  // last row the page table can address
   const int dl = threadIdx.x % LPR, rl = threadIdx.x / LPR;
   const int* list = kept_idx + (size_t)bh * max_seqlen;
   const int* pt = page_table + ((size_t)bmap[b] * H + h) * NLP;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void compact_inplace_kernel(
     for (int p = 0; p < PASSES; ++p) {
       const int j = t0 + p * RPP + rl;
       if (j < cnt) {
-        const size_t a = row_addr(s0 + list[j]);
+        const size_t a = row_addr(s0 + max(0, min(list[j], tok_max)));  // clamped: see compact_store_kernel
         kk[p] = *reinterpret_cast<const uint4*>(kc + a);
         vv[p] = *reinterpret_cast<const uint4*>(vc + a);
       }

@@ -48,15 +48,23 @@ const char* cvllm_error_string(int status);
  * current token); page_table[*,HKV,n_logical_pages_max]; batch_mapping[B]; out[B,HQ,D].
  * n_splits is the number of key splits the kernel uses internally (>=1).  With n_splits > 1 `workspace`
  * (cvllm_decode_workspace_bytes) is required and MUST BE ZERO when first handed to the library; every completed
- * call leaves it zero again.  When B*HKV*n_splits fits the device's CUs the splits are merged inside the one
- * launch (workgroups exchange partials through self-validating mailbox words in the workspace; all of them are
- * resident, every wait is bounded); otherwise fp32 partials are merged by a second kernel.  One workspace serves one
+ * call leaves it zero again.  The splits are merged by a second kernel (fp32 partials; the default), or - opt-in,
+ * CVLLM_DECODE_MERGE=in-launch, and only when B*HKV*n_splits fits the device's CUs - inside the one launch: workgroups
+ * exchange partials through self-validating mailbox words in the workspace.  THE IN-LAUNCH FORM ASSUMES EVERY WORKGROUP
+ * OF THE GRID IS CO-RESIDENT; a plain launch does not guarantee that (CU masks, a shared GPU, a long kernel on another
+ * stream), so every wait is bounded (0.5 s), a timed-out slice is written as NaN and the sticky error word is raised:
+ * callers of that mode must poll cvllm_decode_merge_status.  One workspace serves one
  * stream at a time.  Rows with L==0 produce zeros (reference: uninitialised, quirk Q6).
  * Any n_logical_pages_max is accepted (page ids are windowed through registers 512 at a time).              */
 size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits);
 /* health check (synchronises `stream`): 0 fine, 1 = an in-launch merge timed out since the workspace was zeroed
  * (that call's outputs are NaN; re-zero the workspace), negative = error                                     */
 int cvllm_decode_merge_status(const void* workspace, cvllm_stream_t stream);
+/* process-wide choice of the split merge for grids that fit the chip (host state only): 0 = environment
+ * (CVLLM_DECODE_MERGE=in-launch|two-kernel; default two-kernel), 1 = two-kernel, 2 = in-launch; returns the previous
+ * value.  Not to be flipped between the capture and the replay of a graph that must keep its mode (the mode is baked
+ * into the captured launch).                                                                                   */
+int cvllm_decode_set_merge_mode(int mode);
 int cvllm_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* out,
                       const int32_t* seq_lens_bh, const int32_t* page_table,
                       const int32_t* batch_mapping, void* workspace, size_t workspace_bytes,
@@ -175,13 +183,15 @@ int cvllm_leverage_scores(const void* key_states, int64_t s_n, int64_t s_h, cons
 /* ---- a8: SnapKV window scores -------------------------------------------------------------------
  * replaces compression/snapkv.py:332-448 query_aware_key_scores + :39-157 + :160-276.
  * scores[Nk,HKV] f32 out; rows = last w queries x G heads (w*G <= 256); keys [0, L-w);
- * `pool`-tap trailing mean clipped at 128-key tiles (the reference's autotuned BLOCK_K, pinned;
- * SURVEY P3); last w keys <- +inf; sequences with L <= w are all +inf (reference: uninitialised).
+ * `pool`-tap trailing mean clipped at the start of the key's `pool_tile`-wide block counted from the sequence start:
+ * pool_tile in {32, 64, 128} is the reference's autotuned BLOCK_K of _scores_from_logits_kernel (snapkv.py:160-168,
+ * 253-262), which changes the pooled values; 0 = 128.  Last w keys <- +inf; sequences with L <= w are all +inf
+ * (reference: uninitialised).
  * No fp32 logits buffer: two passes over K with per-tile (max,sum) partials in `workspace`.     */
 size_t cvllm_snapkv_workspace_bytes(int B, int HKV, int w, int max_seqlen_k);
 int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                         float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
-                        int B, int HQ, int HKV, int D, int w, float sm_scale, int pool,
+                        int B, int HQ, int HKV, int D, int w, float sm_scale, int pool, int pool_tile,
                         int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
                         cvllm_stream_t stream);
 /* the same with one window per sequence (snapkv.py:351-357: `w` may be a [B] int32 tensor): window_b[b] <= w_max,
@@ -189,8 +199,8 @@ int cvllm_snapkv_scores(const void* q, const void* k, int64_t sq_n, int64_t sk_n
 int cvllm_snapkv_scores_wb(const void* q, const void* k, int64_t sq_n, int64_t sk_n, int64_t sk_h,
                            float* scores, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                            const int32_t* window_b, int B, int HQ, int HKV, int D, int w_max, float sm_scale,
-                           int pool, int max_seqlen_k, int dtype, void* workspace, size_t workspace_bytes,
-                           cvllm_stream_t stream);
+                           int pool, int pool_tile, int max_seqlen_k, int dtype, void* workspace,
+                           size_t workspace_bytes, cvllm_stream_t stream);
 
 /* ---- a9: joint top-k selection ------------------------------------------------------------------
  * replaces compression/common.py:171-243 scores_to_retain_indices (torch.topk full sort) and the
@@ -207,6 +217,12 @@ int cvllm_select_topk(const float* scores, const int32_t* cu_seqlens_k, const in
                       int32_t* new_lens, int B, int H, int max_seqlen, int page_size,
                       int pad_to_page, int reserved_batch, void* workspace,
                       size_t workspace_bytes, cvllm_stream_t stream);
+/* health check (synchronises `stream`): 0 fine; 1 = since the last check a slice workgroup of the per-head ordered
+ * write (sequences >= 8192 tokens) gave up waiting 0.5 s for the counts of the slices before it - the library never
+ * traps or spins on: that call's kept lists are incomplete (every index still a valid token: the consumers clamp), the
+ * sticky per-device word is cleared by this call; negative = error.  Call it once per prefill, after the store stream
+ * has been joined (compactor_vllm_amd.compression.common.select_status).                                           */
+int cvllm_select_status(cvllm_stream_t stream);
 
 /* ---- a10: compaction -----------------------------------------------------------------------------
  * replaces kv_cache/store_kv_cache.py:81-175 prefill_store_topk_kv (scatter + pad kernels).

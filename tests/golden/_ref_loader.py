@@ -10,7 +10,9 @@ Harness-side pins (the reference files themselves are never modified; see SURVEY
   * a bare namespace package `compactor_vllm` so the top-level __init__ (which needs flash_attn
     and a tokenizer stack) is skipped;
   * one fixed Triton config per autotuned kernel (the autotuner cannot benchmark on CPU);
-  * torch.cuda.device / Tensor.cuda / linalg.svd(driver=) made CPU-neutral;
+  * torch.cuda.device / Tensor.cuda / linalg.svd(driver=) made CPU-neutral; for the host-policy vectors
+    (`load_engine_policy`) also the hard-coded device="cuda" of torch.tensor / torch.empty / torch.as_tensor
+    (kv_cache/page_table.py:185, write_page_table.py:42, core/memory_manager.py:59);
   * bf16 tl.dot up-converted to fp32 in the interpreter (it otherwise multiplies raw uint16 bits).
 """
 import contextlib
@@ -83,3 +85,27 @@ def load():
 
     _I.InterpreterBuilder.create_dot = _dot
     return types.SimpleNamespace(dk=dk, pk=pk, cm=cm, cp=cp, sk=sk, st=st)
+
+
+def load_engine_policy():
+    """The reference's host-side policy classes (page allocator, prefill admission) for tests/golden/gen_fixtures.py
+    `engine_policy`.  Call after load().  Their three hard-coded device="cuda" arguments are redirected to the CPU the
+    same way Tensor.cuda is (harness side; the reference files are untouched)."""
+
+    def cpu_device(fn):
+        def wrapped(*a, **k):
+            if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+                k["device"] = "cpu"
+            return fn(*a, **k)
+
+        return wrapped
+
+    torch.tensor = cpu_device(torch.tensor)
+    torch.empty = cpu_device(torch.empty)
+    torch.as_tensor = cpu_device(torch.as_tensor)
+    import compactor_vllm.core.scheduler as sched
+    import compactor_vllm.kv_cache.page_table as ptab
+    import compactor_vllm.utils.sequence as seq
+    from compactor_vllm.config.sampling_params import SamplingParams
+
+    return types.SimpleNamespace(sched=sched, ptab=ptab, seq=seq, SamplingParams=SamplingParams)

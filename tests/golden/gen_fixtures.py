@@ -388,8 +388,197 @@ def gen_producer():
                   **({"q_norm_w": qw, "k_norm_w": kw} if norm else {}), q_rot=q_rot, k_rot=k_rot, k_pre=k_pre)
 
 
+# ---------------------------------------------------------------------------- a8, the other two autotune outcomes
+def gen_snapkv_tiles():
+    """SnapKV with the reference's `_scores_from_logits_kernel` pinned to BLOCK_K = 32 and 64 (its autotuner picks one
+    of {32, 64, 128}, snapkv.py:160-168; the 5-tap pooling is clipped at BLOCK_K tile edges, :253-262, so the pooled
+    scores differ between the three).  The committed snapkv_* / snapkvx_* sets are the BLOCK_K = 128 outcome."""
+    import triton
+
+    for bk in (32, 64):
+        R.sk._scores_from_logits_kernel.configs = [triton.Config({"BLOCK_Q": 64, "BLOCK_K": bk})]
+        R.sk._scores_from_logits_kernel.cache.clear()
+        for name, dtype, lens, HQ, HKV, D in [
+            (f"snapkvt_f16_bk{bk}", torch.float16, [257, 100, 600], 8, 2, 128),
+            (f"snapkvt_bf16_bk{bk}", torch.bfloat16, [300, 40, 161], 16, 4, 128),
+        ]:
+            g = torch.Generator().manual_seed(12)
+            N = sum(lens)
+            cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+            q = torch.randn(N, HQ, D, generator=g).to(dtype)
+            k = torch.randn(N, HKV, D, generator=g).to(dtype)
+            ref = R.sk.query_aware_key_scores(q, k, cu, cu, w=32)
+            mine = O.snapkv_scores(q, k, cu, cu, 32, pool_tile=bk)
+            other = O.snapkv_scores(q, k, cu, cu, 32, pool_tile=128)
+            fin = torch.isfinite(ref)
+            assert torch.equal(fin, torch.isfinite(mine))
+            print(f"{name}: oracle(pool_tile={bk}) vs reference max|d| = {maxdiff(ref[fin], mine[fin]):.3e}; "
+                  f"oracle(pool_tile=128) would differ by {maxdiff(ref[fin], other[fin]):.3e}")
+            save_case(name, q=q, k=k, cu_seqlens=cu, w=32, HQ=HQ, HKV=HKV, D=D, pool_tile=bk, out=ref)
+    R.sk._scores_from_logits_kernel.configs = [triton.Config({"BLOCK_Q": 64, "BLOCK_K": 128})]
+    R.sk._scores_from_logits_kernel.cache.clear()
+
+
+# -------------------------------------------------------------------- a2 with a RESERVED_BATCH padding row (Q6)
+def gen_decode_reserved():
+    """Decode attention as the engine's graph path calls it: the batch is padded with RESERVED_BATCH (row 0) entries
+    whose lengths are 0 (model_runner.py:468-491; stage 1 returns without writing for L == 0,
+    sparse_decode_kernel.py:281-283).  The reference's output rows of the padded entries are uninitialised memory
+    (torch.empty): the vector stores which rows those are; every other row is the reference's."""
+    for name, dtype, B, HQ, HKV, D, PS, split in [
+        ("decoderes_f16", torch.float16, 4, 8, 2, 128, 128, 2),
+        ("decoderes_bf16", torch.bfloat16, 3, 32, 8, 128, 128, 3),
+    ]:
+        g = torch.Generator().manual_seed(sum(name.encode()) % 10000)
+        lens = torch.randint(1, 500, (B, HKV), generator=g, dtype=torch.int32)
+        lens[0, 0] = 1
+        reserved_rows = [1, B - 1]
+        for rb in reserved_rows:
+            lens[rb] = 0
+        kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens.clamp_min(1), dtype, seed=29)
+        for rb in reserved_rows:
+            bm[rb] = 0
+        q = torch.randn(B, HQ, D, generator=g).to(dtype)
+        scale = 1.0 / math.sqrt(D)
+        ref = R.dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, scale, key_split=split)
+        mine = O.decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, scale)
+        live = torch.tensor([b not in reserved_rows for b in range(B)])
+        print(f"{name}: oracle vs reference on the live rows max|d| = {maxdiff(ref[live], mine[live]):.3e}")
+        save_case(name, q=q, k_cache=kc, v_cache=vc, seq_lens_bh=lens, page_table=pt, batch_mapping=bm, HQ=HQ, HKV=HKV,
+                  D=D, PAGE_SIZE=PS, sm_scale=scale, key_split=split, live_rows=live.to(torch.int32), out=ref)
+
+
+# ------------------------------------------------------------- a1 at BASELINE.json configs[0] (C1): 4096 dense
+def c1_inputs(seed=1234):
+    """Seeded inputs of the C1 case; tests/test_gpu_fullsize.py rebuilds them with the same calls (same torch build)."""
+    N, HQ, HKV, D = 4096, 32, 8, 128
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(N, HQ, D, generator=g).to(torch.float16)
+    k = torch.randn(N, HKV, D, generator=g).to(torch.float16)
+    v = torch.randn(N, HKV, D, generator=g).to(torch.float16)
+    return q, k, v
+
+
+def gen_c1():
+    """BASELINE.json configs[0]: HQ 32 / HKV 8 / D 128 / page 128, 4096 tokens, batch 1, dense causal attention with an
+    empty cache (the shape of tests/test_triton_attention.py:200-287), fp16 - the reference's own kernel under the
+    interpreter (about two minutes).  The 32 MiB output is not committed: 512 sampled (token, head) rows + checksums of
+    the seeded inputs are."""
+    N, HQ, HKV, D, PS = 4096, 32, 8, 128, 128
+    q, k, v = c1_inputs()
+    lens = torch.zeros(1, HKV, dtype=torch.int32)
+    pt = torch.zeros(2, HKV, 1, dtype=torch.int32)
+    bm = torch.tensor([1], dtype=torch.int32)
+    kc = torch.zeros(PS, D, dtype=torch.float16)
+    cu = torch.tensor([0, N], dtype=torch.int32)
+    scale = 1.0 / math.sqrt(D)
+    ref = R.pk.causal_sparse_varlen_with_cache(q, k, v, kc, kc.clone(), lens, pt, bm, cu, N, 0, HKV, PS, scale)
+    g = torch.Generator().manual_seed(99)
+    tok = torch.cat([torch.tensor([0, 1, 63, 64, 127, 128, 4095]), torch.randint(0, N, (505,), generator=g)])
+    head = torch.randint(0, HQ, (tok.numel(),), generator=g)
+    rows = ref[tok, head]
+    mine = O.prefill_attention(q, k, v, kc, kc.clone(), lens, pt, bm, cu, HKV, PS, scale)
+    print(f"c1prefill_4096: oracle vs reference max|d| over the whole output = {maxdiff(ref, mine):.3e}")
+    chk = lambda t: int(t.view(torch.int16).to(torch.int64).sum())
+    save_case("c1prefill_4096", seed=1234, N=N, HQ=HQ, HKV=HKV, D=D, PAGE_SIZE=PS, sm_scale=scale, tok=tok, head=head,
+              rows=rows, q_checksum=chk(q), k_checksum=chk(k), v_checksum=chk(v),
+              out_abs_mean=float(ref.float().abs().mean()))
+
+
+# --------------------------------------------------------- f-1 host policy: page allocator and prefill admission
+def gen_engine_policy():
+    """Traces of the reference's own PagedKVCache (page_table.py:144-291) and Scheduler.get_prefill_batch
+    (scheduler.py:65-108) on scripted operation lists: what they return and the state they leave, as JSON."""
+    import json
+
+    E = _ref_loader.load_engine_policy()
+    L, P, NP, PS, H, MB = 3, 6, 40, 16, 2, 4
+    cache = E.ptab.PagedKVCache(num_layers=L, max_logical_pages_per_head=P, num_pages=NP, page_size=PS, H_kv=H,
+                                head_dim=8, max_num_batches=MB, dtype=torch.float16, device="cpu")
+    g = torch.Generator().manual_seed(5)
+    ops, rows = [], {}
+
+    def snap(ret):
+        st = {"ret": ret, "free_batches": list(cache.free_batches),
+              "free_pages": [sorted(fp) for fp in cache.free_pages],
+              "num_pages": cache.bh_num_pages.tolist(), "lens": cache.bh_seq_lens.tolist(), "tables": {}}
+        for name, r in rows.items():
+            npg = cache.bh_num_pages[:, r]
+            st["tables"][name] = [[cache.page_table[l, r, h, : int(npg[l, h])].tolist() for h in range(H)]
+                                  for l in range(L)]
+        return st
+
+    def do(op, *a):
+        if op == "new_batch":
+            r = cache.new_batch()
+            if r is not None:
+                rows[a[0]] = int(r)
+            ret = r
+        elif op == "reserve":
+            ret = cache.reserve_tokens(rows[a[0]], a[1]).name
+        elif op == "set_lens":  # what the store kernels do on the device: per-(layer, head) lengths
+            cache.bh_seq_lens[:, rows[a[0]]] = torch.tensor(a[1], dtype=torch.int32)
+            ret = None
+        elif op == "reclaim":
+            ret = cache.reclaim_pages(rows[a[0]], a[1])
+        elif op == "free":
+            ret = cache.free_batch(rows.pop(a[0]))
+        ops.append({"op": op, "args": list(a), "after": snap(ret)})
+
+    rl = lambda hi: torch.randint(0, hi + 1, (L, H), generator=g).tolist()
+    do("new_batch", "a"); do("reserve", "a", 50); do("new_batch", "b"); do("reserve", "b", 33)
+    do("set_lens", "a", rl(40)); do("reclaim", "a", 8)            # compression left per-head lengths, 8 new tokens
+    do("reserve", "a", 8); do("reserve", "a", 30)                  # fits / grows
+    do("new_batch", "c"); do("reserve", "c", 97)                   # exceeds max pages per head (6 * 16 = 96)
+    do("reserve", "c", 96); do("new_batch", "d"); do("reserve", "d", 90)   # d: not enough pages left
+    do("set_lens", "b", rl(33)); do("reclaim", "b", 0); do("free", "a")
+    do("reserve", "d", 60); do("new_batch", "e"); do("new_batch", "f")    # rows run out at 4
+    do("free", "c"); do("new_batch", "f"); do("reserve", "f", 16); do("reclaim", "f", 0)
+    do("set_lens", "d", rl(60)); do("reclaim", "d", 5); do("free", "b"); do("free", "d"); do("free", "f"); do("free", "e")
+    alloc = {"config": dict(num_layers=L, max_logical_pages_per_head=P, num_pages=NP, page_size=PS, H_kv=H,
+                            max_num_batches=MB), "ops": ops}
+
+    class Mgr:  # the five attributes get_prefill_batch reads from its KVCacheManager (scheduler.py:84-103)
+        def __init__(s, **k):
+            s.__dict__.update(k)
+
+    sched_cases = []
+    for cname, mk, prompts in [
+        ("token_budget", dict(max_batched_tokens=1000, num_free_batches=8, num_free_pages=10000, page_size=128, num_kv_heads=8),
+         [(400, 16), (500, 16), (200, 16), (100, 16), (90, 16)]),
+        ("rows", dict(max_batched_tokens=100000, num_free_batches=2, num_free_pages=10000, page_size=128, num_kv_heads=8),
+         [(400, 16), (500, 16), (200, 16)]),
+        ("pages_strict", dict(max_batched_tokens=100000, num_free_batches=8, num_free_pages=64, page_size=128, num_kv_heads=8),
+         [(500, 12), (500, 13), (100, 10), (1000, 24), (120, 8), (100, 28)]),
+        ("skip_then_fit", dict(max_batched_tokens=4096, num_free_batches=3, num_free_pages=200, page_size=128, num_kv_heads=8),
+         [(4000, 256), (5000, 1), (96, 256), (1, 1), (1, 1)]),
+        ("nothing_fits", dict(max_batched_tokens=64, num_free_batches=8, num_free_pages=10000, page_size=128, num_kv_heads=8),
+         [(65, 1), (100, 1)]),
+    ]:
+        seqs = [E.seq.Sequence(prompt_token_ids=[1] * pl, sampling_params=E.SamplingParams(max_new_tokens=mn))
+                for pl, mn in prompts]
+        sc = E.sched.Scheduler(seqs, Mgr(**mk), use_tqdm=False)
+        rounds = []
+        for _ in range(4):  # admit, mark running, ask again (pages / rows are the fake manager's: unchanged)
+            batch = sc.get_prefill_batch()
+            rounds.append([seqs.index(s) for s in batch])
+            if not batch:
+                break
+            sc.add_running_sequence_ids([s.seq_id for s in batch], update_status=True)
+        sched_cases.append({"name": cname, "manager": mk, "prompts": prompts, "rounds": rounds,
+                            "total_tokens_input": sc.total_tokens_input})
+        print(f"scheduler {cname}: admitted {rounds}")
+    out = os.path.join(HERE, "engine_policy.json")
+    with open(out, "w") as f:
+        json.dump({"allocator": alloc, "scheduler": sched_cases}, f, separators=(",", ":"))
+    print(f"engine policy: {len(ops)} allocator operations, {len(sched_cases)} admission cases -> {out}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring", "producer", "snapkv_ext"]
+    which = sys.argv[1:] or ["prefill", "decode", "stores", "select", "scoring", "producer", "snapkv_ext",
+                             "snapkv_tiles", "decode_reserved", "c1", "engine_policy"]
     for w in which:
         {"prefill": gen_prefill, "decode": gen_decode, "stores": gen_stores, "select": gen_select,
-         "scoring": gen_scoring, "producer": gen_producer, "snapkv_ext": gen_snapkv_ext}[w]()
+         "scoring": gen_scoring, "producer": gen_producer, "snapkv_ext": gen_snapkv_ext,
+         "snapkv_tiles": gen_snapkv_tiles, "decode_reserved": gen_decode_reserved, "c1": gen_c1,
+         "engine_policy": gen_engine_policy}[w]()

@@ -12,6 +12,17 @@ from oracle import ref_cpu as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["two-kernel", "in-launch"])
+def merge_mode(request, dev):
+    """Both split merges for grids that fit the chip: the default two-kernel path and the opt-in in-launch form
+    (CVLLM_DECODE_MERGE=in-launch / cvllm_decode_set_merge_mode)."""
+    from compactor_vllm_amd.attention import sparse_decode_kernel as dk
+
+    prev = dk.set_merge_mode(request.param)
+    yield request.param
+    dk.set_merge_mode(prev)
+
+
 def _ws_is_zero(dev):
     from compactor_vllm_amd.attention import sparse_decode_kernel as dk
 
@@ -29,9 +40,9 @@ def _ws_is_zero(dev):
     (1, 8, 1, 128, 256, 70000),    # one group, 256 splits would exceed the cap: 128 splits, G = 8
     (7, 14, 7, 64, 32, 1500),      # odd everything, page size 32
 ])
-def test_decode_merge_paths_agree_with_oracle(dev, dtype, B, HQ, HKV, D, PS, maxlen):
-    """The same call through the in-launch merge (default plan: grid <= CUs) and through the two-kernel merge (a
-    key_split hint that oversubscribes the chip) against the fp32 oracle; zero-length heads and a sequence with every
+def test_decode_merge_paths_agree_with_oracle(dev, merge_mode, dtype, B, HQ, HKV, D, PS, maxlen):
+    """The same call with the plan that fits the chip (merged by `merge_mode`) and with a key_split hint that
+    oversubscribes the chip (always the two-kernel merge) against the fp32 oracle; zero-length heads and a sequence with every
     head empty included.  Afterwards the workspace is all zeros again and the merge status is clean."""
     from compactor_vllm_amd.attention import sparse_decode_kernel as dk
 
@@ -62,7 +73,7 @@ def test_decode_merge_paths_agree_with_oracle(dev, dtype, B, HQ, HKV, D, PS, max
     assert _ws_is_zero(dev)
 
 
-def test_decode_in_launch_merge_is_deterministic_under_replay(dev):
+def test_decode_in_launch_merge_is_deterministic_under_replay(dev, merge_mode):
     """Back-to-back launches on one workspace (what a decode step's 32 layers and a HIP-graph replay do): every launch
     returns the same bits, eagerly and from a captured graph."""
     from compactor_vllm_amd.attention import sparse_decode_kernel as dk
@@ -157,7 +168,7 @@ def test_decode_page_table_wider_than_register_window(dev, B, long_len):
     assert dk.merge_status(dev) == 0
 
 
-def test_fused_append_with_in_launch_merge_matches_store_then_attend(dev):
+def test_fused_append_with_in_launch_merge_matches_store_then_attend(dev, merge_mode):
     """cvllm_decode_append_attn (new row substituted from registers, written by the owning split, length published by
     split 0 after its mailbox filled) == decode_store_kv followed by the attention call, bit for bit, over several
     consecutive steps that cross a page boundary."""

@@ -91,3 +91,110 @@ def test_engine_compression_really_evicts_and_reclaims(dev):
     # uncompressed: ceil(908 / 128) = 8 pages x 2 heads = 16 per layer held; after reclaim far fewer
     assert seen["free_pages"] > 40 - 16
     assert runner.kv_manager.num_free_pages == 40
+
+
+@pytest.mark.parametrize("method_name,ratio", [("COMPACTOR", 0.5), ("SNAPKV", 0.25), ("NONE", 1.0)])
+def test_engine_prefill_cache_and_first_decode_step_equal_oracle(dev, method_name, ratio):
+    """The oracle leg of the engine loop (f-1): what `LLM.generate` leaves behind is checked against the CPU oracle,
+    layer by layer, not against another run of the engine.  Spies on every layer's `Attention.forward` record what the
+    engine fed it; then, per layer:
+      * prefill output == oracle.prefill_attention on the recorded q / k / v (empty cache);
+      * per-head lengths after the prefill == oracle.retained_sets fed with THAT layer's score tensor and the engine's
+        retain counts, and the cache rows of every (sequence, head) == the retained tokens' K / V rows, in token order;
+      * the first decode step's attention output == dense softmax attention over {retained rows} U {new token}, and the
+        lengths grew by one."""
+    import math
+
+    from compactor_vllm_amd import BatchCompressionParams, CompressionMethod, SamplingParams, SequenceCompressionParams
+    from compactor_vllm_amd.core.memory_manager import attention_modules
+    from compactor_vllm_amd.utils.context import get_context
+    from helpers import tol
+    from oracle import ref_cpu as O
+
+    method = CompressionMethod[method_name]
+    llm = _llm(dev, eager=True, num_pages=60, max_num_seqs=4, max_batched_tokens=2048)
+    runner = llm.master_model_runner
+    attns = attention_modules(runner.model)
+    prefill, decode = {}, {}
+
+    def install(li, attn):
+        orig = attn.forward
+
+        def spy(q, k, v, scores=None):
+            ctx = get_context()
+            torch.cuda.synchronize()  # the score tensor is produced on the store stream
+            bm = ctx.batch_mapping.long()
+            before = attn.bh_seq_lens.index_select(0, bm).cpu()
+            rec = dict(q=q.cpu(), k=k.cpu(), v=v.cpu(), bm=ctx.batch_mapping.cpu(), before=before,
+                       scores=None if scores is None else scores.float().cpu())
+            if ctx.is_prefill:
+                rec["cu"] = ctx.cu_seqlens_k.cpu()
+                cc = ctx.compression_context
+                rec["retain"] = None if cc is None or not ctx.do_compression else cc.batch_tokens_to_retain.cpu()
+            out = orig(q, k, v, scores)
+            torch.cuda.synchronize()
+            rec["out"] = out.cpu()
+            rec["after"] = attn.bh_seq_lens.index_select(0, bm).cpu()
+            if ctx.is_prefill:
+                pt, PS = attn.page_table.cpu(), attn.page_size
+                kc, vc = attn.k_cache.cpu(), attn.v_cache.cpu()
+                rows = [[O.cache_rows(pt[int(rec["bm"][b]), h], int(rec["after"][b, h]), PS)
+                         for h in range(attn.num_kv_heads)] for b in range(bm.numel())]
+                rec["k_rows"] = [[kc[r] for r in per_b] for per_b in rows]
+                rec["v_rows"] = [[vc[r] for r in per_b] for per_b in rows]
+                assert li not in prefill, "one prefill wave expected"
+                prefill[li] = rec
+            elif li not in decode:
+                decode[li] = rec  # first decode step only
+            return out
+
+        attn.forward = spy
+
+    for li, attn in enumerate(attns):
+        install(li, attn)
+    g = torch.Generator().manual_seed(17)
+    lens = [700, 300, 45]
+    prompts = [torch.randint(0, 512, (L,), generator=g).tolist() for L in lens]
+    first, last = 4, 16
+    llm.generate(prompts, SamplingParams(temperature=0.0, max_new_tokens=3), BatchCompressionParams(compression_method=method),
+                 per_sequence_compression_params=[SequenceCompressionParams(ratio, first, last) for _ in prompts])
+    assert len(prefill) == len(attns) and len(decode) == len(attns)
+    cfg = runner.model.cfg
+    HQ, HKV, D, PS = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, 128
+    G = HQ // HKV
+    dtype = torch.bfloat16
+    B = len(lens)
+    for li in range(len(attns)):
+        p, d = prefill[li], decode[li]
+        cu = p["cu"]
+        assert cu.diff().tolist() == lens and (p["before"] == 0).all()
+        lens0 = torch.zeros(B, HKV, dtype=torch.int32)
+        dummy = torch.zeros(PS, D, dtype=dtype)
+        ref_o = O.prefill_attention(p["q"], p["k"], p["v"], dummy, dummy, lens0, torch.zeros(8, HKV, 1, dtype=torch.int32),
+                                    p["bm"], cu, HKV, PS, 1.0 / math.sqrt(D))
+        assert torch.allclose(p["out"].float(), ref_o.float(), atol=tol(dtype)), li
+        if method == CompressionMethod.NONE:
+            kept = [[list(range(L)) for _ in range(HKV)] for L in lens]
+            assert torch.equal(p["after"], torch.tensor(lens, dtype=torch.int32)[:, None].repeat(1, HKV))
+        else:
+            want = [O.retain_count(ratio, L, first, last, HKV) for L in lens]
+            assert p["retain"].tolist() == want, li  # the engine's retain counts are the reference formula's
+            kept, lens_o = O.retained_sets(p["scores"], cu, p["retain"], lens0, p["bm"], PS, True)
+            assert torch.equal(p["after"], lens_o), (li, p["after"].tolist(), lens_o.tolist())
+            assert torch.isinf(p["scores"]).any()  # protected tokens present in the engine's score tensor
+        for b in range(B):
+            for h in range(HKV):
+                src = [int(cu[b]) + t for t in sorted(kept[b][h])]
+                assert torch.equal(p["k_rows"][b][h], p["k"][src, h]), (li, b, h)
+                assert torch.equal(p["v_rows"][b][h], p["v"][src, h]), (li, b, h)
+        # first decode step: the decode batch holds the same cache rows (possibly in another order)
+        order = [p["bm"].tolist().index(r) for r in d["bm"].tolist()]
+        assert sorted(order) == list(range(B))
+        assert torch.equal(d["before"], p["after"][order]) and torch.equal(d["after"], d["before"] + 1)
+        for i, b in enumerate(order):
+            for h in range(HKV):
+                src = [int(cu[b]) + t for t in sorted(kept[b][h])]
+                K = torch.cat([p["k"][src, h], d["k"][i, h][None]]).float()
+                V = torch.cat([p["v"][src, h], d["v"][i, h][None]]).float()
+                pr = torch.softmax(d["q"][i, h * G : (h + 1) * G].float() @ K.T / math.sqrt(D), -1)
+                assert torch.allclose(d["out"][i, h * G : (h + 1) * G].float(), pr @ V, atol=tol(dtype)), (li, b, h)

@@ -202,3 +202,67 @@ def test_producer_oracle(name):
     q, k, v, k_pre = O.qkv_producer(c["qkv"], c["positions"], cs, HQ, HKV, D, c.get("q_norm_w"), c.get("k_norm_w"), c["eps"])
     assert torch.equal(q, c["q_rot"]) and torch.equal(k, c["k_rot"]) and torch.equal(k_pre, c["k_pre"])
     assert torch.equal(v.reshape(v.shape[0], -1), c["qkv"][:, (HQ + HKV) * D :])
+
+
+# ------------------------------------------------------------------- round 3: the corners SURVEY 8(c) lists
+@pytest.mark.parametrize("name", list_cases("snapkvt_"))
+def test_snapkv_oracle_pool_tiles(name):
+    """SnapKV with the reference's pooling kernel pinned to BLOCK_K = 32 / 64 (the other two outcomes of its autotuner,
+    snapkv.py:160-168, :253-262): the oracle's `pool_tile` reproduces them, and the 128 outcome does NOT (so the
+    argument matters)."""
+    c = load_case(name)
+    out = O.snapkv_scores(c["q"], c["k"], c["cu_seqlens"], c["cu_seqlens"], c["w"], pool_tile=c["pool_tile"])
+    other = O.snapkv_scores(c["q"], c["k"], c["cu_seqlens"], c["cu_seqlens"], c["w"], pool_tile=128)
+    ref = c["out"]
+    s, differs = 0, False
+    for L in c["cu_seqlens"].diff().tolist():
+        if L > c["w"]:
+            a, r, o = out[s : s + L], ref[s : s + L], other[s : s + L]
+            fin = torch.isfinite(r)
+            assert torch.equal(fin, torch.isfinite(a))
+            assert torch.allclose(a[fin], r[fin], rtol=1e-4, atol=1e-5)
+            differs |= not torch.allclose(o[fin], r[fin], rtol=1e-3, atol=1e-3)
+        s += L
+    assert differs
+
+
+@pytest.mark.parametrize("name", list_cases("decoderes_"))
+def test_decode_oracle_reserved_rows(name):
+    """Decode attention with RESERVED_BATCH padding entries (lengths 0, batch_mapping 0: the engine's graph path,
+    model_runner.py:468-491).  Live rows equal the reference; the padded rows are uninitialised upstream (Q6) and zeros
+    in the oracle."""
+    c = load_case(name)
+    out = O.decode_attention(c["q"], c["k_cache"], c["v_cache"], c["seq_lens_bh"], c["page_table"],
+                             c["batch_mapping"], c["HKV"], c["PAGE_SIZE"], c["sm_scale"])
+    live = c["live_rows"].bool()
+    assert (~live).any()
+    assert torch.allclose(out[live].float(), c["out"][live].float(), rtol=1e-6, atol=tol(c["q"].dtype))
+    assert (out[~live] == 0).all()
+
+
+def c1_inputs(c):
+    """Seeded inputs of the C1 vector (same calls as tests/golden/gen_fixtures.py::c1_inputs), checked by checksum."""
+    N, HQ, HKV, D = c["N"], c["HQ"], c["HKV"], c["D"]
+    g = torch.Generator().manual_seed(c["seed"])
+    q = torch.randn(N, HQ, D, generator=g).to(torch.float16)
+    k = torch.randn(N, HKV, D, generator=g).to(torch.float16)
+    v = torch.randn(N, HKV, D, generator=g).to(torch.float16)
+    chk = lambda t: int(t.view(torch.int16).to(torch.int64).sum())
+    if (chk(q), chk(k), chk(v)) != (c["q_checksum"], c["k_checksum"], c["v_checksum"]):
+        pytest.skip("this torch build draws a different randn stream than the one the C1 vector was made with")
+    return q, k, v
+
+
+def test_prefill_oracle_c1_4096():
+    """BASELINE.json configs[0]: 4096-token dense causal prefill, HQ 32 / HKV 8 / D 128 / page 128, fp16 - the
+    reference's kernel run under the interpreter; 512 sampled output rows are committed."""
+    c = load_case("c1prefill_4096")
+    q, k, v = c1_inputs(c)
+    HKV, PS, D = c["HKV"], c["PAGE_SIZE"], c["D"]
+    kc = torch.zeros(PS, D, dtype=torch.float16)
+    out = O.prefill_attention(q, k, v, kc, kc.clone(), torch.zeros(1, HKV, dtype=torch.int32),
+                              torch.zeros(2, HKV, 1, dtype=torch.int32), torch.tensor([1], dtype=torch.int32),
+                              torch.tensor([0, c["N"]], dtype=torch.int32), HKV, PS, c["sm_scale"])
+    rows = out[c["tok"].long(), c["head"].long()]
+    assert torch.allclose(rows.float(), c["rows"].float(), rtol=1e-6, atol=tol(torch.float16))
+    assert abs(float(out.float().abs().mean()) - c["out_abs_mean"]) < 1e-4

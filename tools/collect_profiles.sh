@@ -15,19 +15,17 @@ cp "$(find "$O/kt" -name '*kernel_stats.csv' | head -1)" "$O/${R}_bench_c3_kerne
 grep "^{\"metric\"" "$O/bench_under_rocprof.log" | tail -1 > "$O/${R}_bench_c3_under_rocprof.json"
 rm -rf "$O/kt"
 echo "[1/7] kernel trace done"
-# 2. HBM traffic of the decode-attention kernel INSIDE bench.py (separate --pmc passes).  Counter collection over every
-#    dispatch of bench.py makes rocprofv3 segfault inside its dispatch callback (with and without HIP graphs; the tiny
-#    workload survives): the collection is therefore limited to the roofline kernel with --kernel-include-regex.
+# 2. HBM traffic of the decode-attention kernel INSIDE bench.py (separate --pmc passes), collection limited to the
+#    roofline kernel with --kernel-include-regex.  (An UNFILTERED --pmc pass over every dispatch of bench.py aborted
+#    twice in round 2 with SIGSEGV - profiles/r02_pmc_unfiltered_crash.log; cause not established, see DESIGN.md
+#    section 6 - and is deliberately NOT re-run here: the existing log is the record.)
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_fused --kernel-trace --output-format csv -d "$O/pf" -- $B > "$O/pmc_fetch.log" 2>&1
 echo "pmc FETCH_SIZE rc=$?" >> "$O/pmc_fetch.log"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex decode_fused --kernel-trace --output-format csv -d "$O/pw" -- $B > "$O/pmc_write.log" 2>&1
 echo "pmc WRITE_SIZE rc=$?" >> "$O/pmc_write.log"
 ALG=$(python3 -c "import json,sys;print(json.load(open('$O/${R}_bench_c3_under_rocprof.json'))['roofline']['algorithmic_bytes_per_launch'])")
 python3 tools/pmc_summary.py "$O/pf" "$O/pw" decode_fused --command "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-include-regex decode_fused --kernel-trace -- $B" --workload C3 --alg-bytes "$ALG" > "$O/${R}_bench_pmc.json"
-# the unfiltered pass, kept as the record of the crash (its log names the faulting frame)
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pall" -- $B > "$O/pmc_unfiltered_crash.log" 2>&1
-echo "unfiltered pmc rc=$?" >> "$O/pmc_unfiltered_crash.log"
-rm -rf "$O/pf" "$O/pw" "$O/pall"
+rm -rf "$O/pf" "$O/pw"
 echo "[2/7] decode PMC done"
 # 3. SQ counters of the prefill kernel (two passes of 8 counters)
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/s1" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq1.log" 2>&1

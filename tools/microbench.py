@@ -144,8 +144,17 @@ def bench_scoring(args):
         ("select + compaction", store_top),
         ("store_all", store_all),
     ]
+    if args.with_producer:
+        from compactor_vllm_amd.layers.rotary_embedding import fused_qkv_rope, get_rope
+        rope = get_rope(D, D, max(L, 1024), 500000.0, None).to(dev)
+        qkv = torch.randn(N, (HQ + 2 * HKV) * D, device=dev).to(dtype)
+        pos = torch.arange(L, device=dev).repeat(B)
+        items.append(("qkv split + rope producer", lambda: fused_qkv_rope(qkv, pos, rope.cos_sin_cache, HQ, HKV, D)))
+    if args.only:
+        items = [it for it in items if args.only in it[0]]
     for name, fn in items:
-        us = time_fn(fn, iters=50, warmup=300)  # ~30 ms of warm calls: settled clocks (3 warm calls read 5-15 % higher)
+        # default ~30 ms of warm calls: settled clocks (3 warm calls read 5-15 % higher)
+        us = time_fn(fn, iters=args.iters or 50, warmup=args.warmup if args.warmup >= 0 else 300)
         print(f"scoring B={B} L={L}: {name:42s} {us:9.1f} us", flush=True)
 
 
@@ -156,5 +165,9 @@ if __name__ == "__main__":
     ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--iters", type=int, default=0)      # scoring: timed calls per item (0 = default)
+    ap.add_argument("--warmup", type=int, default=-1)    # scoring: warm calls per item (-1 = default)
+    ap.add_argument("--with-producer", action="store_true")  # scoring: add the f-2 producer kernel
+    ap.add_argument("--only", default="")                # scoring: substring filter on the item name
     a = ap.parse_args()
     {"decode": bench_decode, "prefill": bench_prefill, "scoring": bench_scoring}[a.what](a)
