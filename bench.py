@@ -118,14 +118,22 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
             dk.head_sparse_decode_attention(q, a.k_cache, a.v_cache, lens_all[li], a.page_table, bm, cfg.kv_heads,
                                             a.page_size)
 
-    one_pass()  # warm-up (workspace allocation)
-    torch.cuda.synchronize()
     if use_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # warm-up AND capture on one side stream: the decode workspace is per stream, so it must exist on the capture
+        # stream before the capture starts (nothing is allocated or zeroed inside the captured region)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
             one_pass()
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                one_pass()
+        torch.cuda.current_stream(dev).wait_stream(side)
         replay = graph.replay
     else:  # --no-graph (the rocprofv3 --pmc passes): the same launches issued eagerly
+        one_pass()  # warm-up (workspace allocation)
+        torch.cuda.synchronize()
         replay = one_pass
     # warm replays for ~50 ms before the timed ones, so that the clocks have settled under this load
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,21 +156,44 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
     achieved = avg_bytes / avg_s / 1e9
     n_splits = dk.plan_internal_splits(B * cfg.kv_heads, model.attn[0].page_table.shape[-1] * model.attn[0].page_size,
                                        None)
-    one_kernel = B * cfg.kv_heads * n_splits <= dk._cus(dev.index)
+    fits = B * cfg.kv_heads * n_splits <= dk._cus(dev.index)
+    one_kernel = n_splits == 1 or (fits and os.environ.get("CVLLM_DECODE_MERGE", "").startswith("i"))
     traffic, traffic_src = pmc_traffic(workload, int(avg_bytes))
-    return {"bound": "hbm",
-            "kernel": "decode_fused_kernel (K/V streaming + in-launch split merge: the whole of reference a2)"
-                      if one_kernel else "decode_fused_kernel + decode_stage2_kernel (reference a2)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
-            "splits": n_splits, "launches_per_layer": 1 if one_kernel else 2, "merge_included": True,
-            "merge_status_ok": merge_ok,
-            "timing": f"one HIP event pair on the launch stream around {rounds} queued "
-                      + ("replays of a HIP graph holding" if use_graph else "eager passes of")
-                      + f" the product's decode-attention call of all {nl} layers back to back (each on its own cache), "
-                      f"divided by {rounds * nl}; includes the inter-launch dispatch gap; ~50 ms of untimed replays "
-                      f"first (clocks settled: a cold leg of 5 replays read 4 % / 15 % lower at 1 / 4 sequences)"}
+    out = {"bound": "hbm",
+           "kernel": "decode_fused_kernel (K/V streaming + in-launch split merge: the whole of reference a2)"
+                     if one_kernel else "decode_fused_kernel + decode_stage2_kernel (K/V streaming, then the split merge: "
+                                        "together the whole of reference a2)",
+           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+           "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+           "splits": n_splits, "launches_per_layer": 1 if one_kernel else 2, "merge_included": True,
+           "merge_status_ok": merge_ok,
+           "timing": f"one HIP event pair on the launch stream around {rounds} queued "
+                     + ("replays of a HIP graph holding" if use_graph else "eager passes of")
+                     + f" the product's decode-attention call of all {nl} layers back to back (each on its own cache), "
+                     f"divided by {rounds * nl}; includes the inter-launch dispatch gaps; ~50 ms of untimed replays "
+                     f"first (clocks settled)"}
+    rp = rocprof_decode(workload, int(avg_bytes))
+    if rp is not None:
+        out["rocprof"] = rp
+    return out
+
+
+def rocprof_decode(workload, alg_bytes):
+    """The same launch's duration as rocprofv3 --kernel-trace saw it over THIS command (the newest committed
+    profiles/*_bench_decode_rocprof.json, written by tools/collect_profiles.sh from the kernel trace of bench.py): mean
+    kernel duration(s) of one layer's decode attention, summed over its launches, and the fraction they give.  A trace
+    cannot be taken from inside the benchmark; None when no matching record is committed."""
+    try:
+        names = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_bench_decode_rocprof.json"))
+        d = json.load(open(os.path.join(ROOT, "profiles", names[-1])))
+        if d.get("workload") != workload or abs(d["algorithmic_bytes_per_launch"] - alg_bytes) > 0.02 * alg_bytes:
+            return None
+        us = float(d["mean_us_per_layer"])
+        return {"avg_launch_us": round(us, 2), "frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels": d.get("kernels"), "source": f"profiles/{names[-1]} ({d.get('command', '')})"}
+    except Exception:  # noqa: BLE001
+        return None
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
@@ -336,6 +367,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-multi-seq", action="store_true", help="skip the extra 4-sequences-per-GPU leg (N=1 only)")
+    ap.add_argument("--serial-store", action="store_true",
+                    help="A/B: run the scoring / selection / compaction chain on the main stream instead of the store stream")
+    ap.add_argument("--no-roofline", action="store_true", help="A/B runs: only the tokens/s line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -393,8 +427,19 @@ def main():
                      kvcache_page_size=page, enforce_eager=args.no_graph, show_progress_bar=False)
     llm = LLM(conf, model, device=dev, num_pages=max_seqs * cfg.kv_heads * (-(-(ctx + new) // page)) + 8,
               max_batched_tokens=max(ctx, min(nseq * ctx, 262144)))
-    g = torch.Generator().manual_seed(1 + rank)
-    prompts = [torch.randint(0, cfg.vocab, (ctx,), generator=g).tolist() for _ in range(nseq)]
+    if args.serial_store:
+        llm.master_model_runner.store_stream = None  # maybe_execute_in_stream(STORE_STREAM=None) runs inline
+    # The job's request list is GLOBAL (world x nseq requests, request i drawn from seed 1 + i) and every rank takes its
+    # share by the longest-processing-time-first partition on L^2 + ratio * L * new (bench_dist.partition_lpt: the same
+    # deterministic partition on every rank, nothing communicated) - sequences shard across replicas, no collective.
+    import bench_dist
+
+    n_req = world * nseq
+    costs = [bench_dist.request_cost(ctx, new, ratio)] * n_req
+    mine = bench_dist.partition_lpt(costs, world)[rank]
+    assert len(mine) == nseq
+    prompts = [torch.randint(0, cfg.vocab, (ctx,), generator=torch.Generator().manual_seed(1 + i)).tolist() for i in mine]
+    g = torch.Generator().manual_seed(1000 + rank)
     # `new` tokens per sequence: the one sampled from the prefill logits + (new - 1) decode steps (quirk Q11 of the
     # reference's loop: max_new_tokens counts decode steps)
     sampling = SamplingParams(temperature=0.0, max_new_tokens=new - 1)
@@ -447,13 +492,17 @@ def main():
         "config": {
             "workload": f"{args.workload}: {cfg.name} random weights, {ctx}-token prefill + {new} decode per sequence, "
                         f"{method_name} ratio {ratio} (protected 16/64, chunk 512), {nseq} sequence(s) per GPU, "
-                        f"store-stream overlapped scoring+eviction, HIP-graph decode, driven by the product's engine "
+                        f"{'scoring+eviction serial on the main stream (A/B)' if args.serial_store else 'store-stream overlapped scoring+eviction'}, "
+                        f"{'eager' if args.no_graph else 'HIP-graph'} decode, driven by the product's engine "
                         f"(LLM.generate: scheduler, paged KV cache, continuous batching)",
             "ctx": ctx, "new_tokens": new, "method": method_name, "ratio": ratio, "sequences_per_gpu": nseq,
-            "parallelism": f"replicas x{world} (sequences sharded, no collectives)",
+            "parallelism": f"replicas x{world} (a global list of {n_req} requests sharded by bench_dist.partition_lpt, "
+                           f"no collectives)",
         },
     }
-    if rank == 0:
+    if rank == 0 and args.no_roofline:
+        print(json.dumps(result), flush=True)
+    elif rank == 0:
         state = prefill_only(llm, prompts, bcp, ratio)  # a prefill whose cache stays allocated: the real cache
         result["roofline"] = roofline_decode_attn(model, state, args.workload, use_graph=not args.no_graph)
         copy_bw = copy_bandwidth_gbs(dev)

@@ -27,6 +27,9 @@ FILE_FLAGS = {"prefill_attn.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vg
               "decode_attn.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 
 
+AUDITED = {"prefill_attn.hip"}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -59,6 +62,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        if os.path.basename(src) in AUDITED:
+            # asm-owned accumulator registers (prefill_attn.hip, pv_mfma): the same compile to assembly, audited
+            asm = obj[:-2] + ".s"
+            subprocess.run([_hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "--cuda-device-only", "-S",
+                            src, "-o", asm], check=True)
+            subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "audit_acc_regs.py"), asm],
+                           check=True)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:

@@ -42,6 +42,173 @@ __device__ __forceinline__ f32x16 mfma32<BF16>(s16x8 a, s16x8 b, f32x16 c) {
                                                  0);
 }
 
+// The 4-wave kernel's output accumulators O^T (2 query blocks x 4 head-dim blocks x 16 registers) live in the ACC
+// registers a[128:255], owned by inline asm (the structure the CDNA guide names for this kernel shape).  Why: the kernel
+// is built with -amdgpu-mfma-vgpr-form so that hipcc's own MFMAs - the QK^T chains, whose results the VALU reads and
+// whose accumulator seed is an arch-VGPR block (negm) - take and deliver arch VGPRs; an MFMA's C and D share one
+// register-file bit, so hipcc would keep the 128 output accumulators in arch VGPRs as well: half of the file, and the
+// seed blocks no longer fit.  Here the PV MFMAs name their accumulator registers literally; the compiler allocates ITS
+// AGPRs from a0 upwards and must stay below a128 (build.py audits the code object: no compiler-emitted instruction may
+// touch a128+).  hipcc pads no hazards around an asm statement: the two places that access these registers with
+// v_accvgpr_* (rare rescale, epilogue) wait out the MFMA pipeline themselves (acc_settle) and pad their writes.
+constexpr int P4_ACC0 = 128;
+template <typename T, int X>
+__device__ __forceinline__ void pv_mfma(s16x8 a, s16x8 b) {
+  static_assert(X >= P4_ACC0 && X + 15 < 256 && (X % 16) == 0, "accumulator block");
+  if constexpr (std::is_same<T, BF16>::value)
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(X), "i"(X + 15));
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(X), "i"(X + 15));
+}
+template <int R>
+__device__ __forceinline__ float acc_read() {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(t) : "i"(R));
+  return t;
+}
+template <int R>
+__device__ __forceinline__ void acc_write(float t) {
+  asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(t), "i"(R));
+}
+// a[128:255] = 0; the clobber list is what makes the kernel descriptor allocate the registers
+__device__ __forceinline__ void acc_zero_all() {
+  asm volatile(
+      "v_accvgpr_write_b32 a128, 0\n\t"
+      "v_accvgpr_write_b32 a129, 0\n\t"
+      "v_accvgpr_write_b32 a130, 0\n\t"
+      "v_accvgpr_write_b32 a131, 0\n\t"
+      "v_accvgpr_write_b32 a132, 0\n\t"
+      "v_accvgpr_write_b32 a133, 0\n\t"
+      "v_accvgpr_write_b32 a134, 0\n\t"
+      "v_accvgpr_write_b32 a135, 0\n\t"
+      "v_accvgpr_write_b32 a136, 0\n\t"
+      "v_accvgpr_write_b32 a137, 0\n\t"
+      "v_accvgpr_write_b32 a138, 0\n\t"
+      "v_accvgpr_write_b32 a139, 0\n\t"
+      "v_accvgpr_write_b32 a140, 0\n\t"
+      "v_accvgpr_write_b32 a141, 0\n\t"
+      "v_accvgpr_write_b32 a142, 0\n\t"
+      "v_accvgpr_write_b32 a143, 0\n\t"
+      "v_accvgpr_write_b32 a144, 0\n\t"
+      "v_accvgpr_write_b32 a145, 0\n\t"
+      "v_accvgpr_write_b32 a146, 0\n\t"
+      "v_accvgpr_write_b32 a147, 0\n\t"
+      "v_accvgpr_write_b32 a148, 0\n\t"
+      "v_accvgpr_write_b32 a149, 0\n\t"
+      "v_accvgpr_write_b32 a150, 0\n\t"
+      "v_accvgpr_write_b32 a151, 0\n\t"
+      "v_accvgpr_write_b32 a152, 0\n\t"
+      "v_accvgpr_write_b32 a153, 0\n\t"
+      "v_accvgpr_write_b32 a154, 0\n\t"
+      "v_accvgpr_write_b32 a155, 0\n\t"
+      "v_accvgpr_write_b32 a156, 0\n\t"
+      "v_accvgpr_write_b32 a157, 0\n\t"
+      "v_accvgpr_write_b32 a158, 0\n\t"
+      "v_accvgpr_write_b32 a159, 0\n\t"
+      "v_accvgpr_write_b32 a160, 0\n\t"
+      "v_accvgpr_write_b32 a161, 0\n\t"
+      "v_accvgpr_write_b32 a162, 0\n\t"
+      "v_accvgpr_write_b32 a163, 0\n\t"
+      "v_accvgpr_write_b32 a164, 0\n\t"
+      "v_accvgpr_write_b32 a165, 0\n\t"
+      "v_accvgpr_write_b32 a166, 0\n\t"
+      "v_accvgpr_write_b32 a167, 0\n\t"
+      "v_accvgpr_write_b32 a168, 0\n\t"
+      "v_accvgpr_write_b32 a169, 0\n\t"
+      "v_accvgpr_write_b32 a170, 0\n\t"
+      "v_accvgpr_write_b32 a171, 0\n\t"
+      "v_accvgpr_write_b32 a172, 0\n\t"
+      "v_accvgpr_write_b32 a173, 0\n\t"
+      "v_accvgpr_write_b32 a174, 0\n\t"
+      "v_accvgpr_write_b32 a175, 0\n\t"
+      "v_accvgpr_write_b32 a176, 0\n\t"
+      "v_accvgpr_write_b32 a177, 0\n\t"
+      "v_accvgpr_write_b32 a178, 0\n\t"
+      "v_accvgpr_write_b32 a179, 0\n\t"
+      "v_accvgpr_write_b32 a180, 0\n\t"
+      "v_accvgpr_write_b32 a181, 0\n\t"
+      "v_accvgpr_write_b32 a182, 0\n\t"
+      "v_accvgpr_write_b32 a183, 0\n\t"
+      "v_accvgpr_write_b32 a184, 0\n\t"
+      "v_accvgpr_write_b32 a185, 0\n\t"
+      "v_accvgpr_write_b32 a186, 0\n\t"
+      "v_accvgpr_write_b32 a187, 0\n\t"
+      "v_accvgpr_write_b32 a188, 0\n\t"
+      "v_accvgpr_write_b32 a189, 0\n\t"
+      "v_accvgpr_write_b32 a190, 0\n\t"
+      "v_accvgpr_write_b32 a191, 0\n\t"
+      "v_accvgpr_write_b32 a192, 0\n\t"
+      "v_accvgpr_write_b32 a193, 0\n\t"
+      "v_accvgpr_write_b32 a194, 0\n\t"
+      "v_accvgpr_write_b32 a195, 0\n\t"
+      "v_accvgpr_write_b32 a196, 0\n\t"
+      "v_accvgpr_write_b32 a197, 0\n\t"
+      "v_accvgpr_write_b32 a198, 0\n\t"
+      "v_accvgpr_write_b32 a199, 0\n\t"
+      "v_accvgpr_write_b32 a200, 0\n\t"
+      "v_accvgpr_write_b32 a201, 0\n\t"
+      "v_accvgpr_write_b32 a202, 0\n\t"
+      "v_accvgpr_write_b32 a203, 0\n\t"
+      "v_accvgpr_write_b32 a204, 0\n\t"
+      "v_accvgpr_write_b32 a205, 0\n\t"
+      "v_accvgpr_write_b32 a206, 0\n\t"
+      "v_accvgpr_write_b32 a207, 0\n\t"
+      "v_accvgpr_write_b32 a208, 0\n\t"
+      "v_accvgpr_write_b32 a209, 0\n\t"
+      "v_accvgpr_write_b32 a210, 0\n\t"
+      "v_accvgpr_write_b32 a211, 0\n\t"
+      "v_accvgpr_write_b32 a212, 0\n\t"
+      "v_accvgpr_write_b32 a213, 0\n\t"
+      "v_accvgpr_write_b32 a214, 0\n\t"
+      "v_accvgpr_write_b32 a215, 0\n\t"
+      "v_accvgpr_write_b32 a216, 0\n\t"
+      "v_accvgpr_write_b32 a217, 0\n\t"
+      "v_accvgpr_write_b32 a218, 0\n\t"
+      "v_accvgpr_write_b32 a219, 0\n\t"
+      "v_accvgpr_write_b32 a220, 0\n\t"
+      "v_accvgpr_write_b32 a221, 0\n\t"
+      "v_accvgpr_write_b32 a222, 0\n\t"
+      "v_accvgpr_write_b32 a223, 0\n\t"
+      "v_accvgpr_write_b32 a224, 0\n\t"
+      "v_accvgpr_write_b32 a225, 0\n\t"
+      "v_accvgpr_write_b32 a226, 0\n\t"
+      "v_accvgpr_write_b32 a227, 0\n\t"
+      "v_accvgpr_write_b32 a228, 0\n\t"
+      "v_accvgpr_write_b32 a229, 0\n\t"
+      "v_accvgpr_write_b32 a230, 0\n\t"
+      "v_accvgpr_write_b32 a231, 0\n\t"
+      "v_accvgpr_write_b32 a232, 0\n\t"
+      "v_accvgpr_write_b32 a233, 0\n\t"
+      "v_accvgpr_write_b32 a234, 0\n\t"
+      "v_accvgpr_write_b32 a235, 0\n\t"
+      "v_accvgpr_write_b32 a236, 0\n\t"
+      "v_accvgpr_write_b32 a237, 0\n\t"
+      "v_accvgpr_write_b32 a238, 0\n\t"
+      "v_accvgpr_write_b32 a239, 0\n\t"
+      "v_accvgpr_write_b32 a240, 0\n\t"
+      "v_accvgpr_write_b32 a241, 0\n\t"
+      "v_accvgpr_write_b32 a242, 0\n\t"
+      "v_accvgpr_write_b32 a243, 0\n\t"
+      "v_accvgpr_write_b32 a244, 0\n\t"
+      "v_accvgpr_write_b32 a245, 0\n\t"
+      "v_accvgpr_write_b32 a246, 0\n\t"
+      "v_accvgpr_write_b32 a247, 0\n\t"
+      "v_accvgpr_write_b32 a248, 0\n\t"
+      "v_accvgpr_write_b32 a249, 0\n\t"
+      "v_accvgpr_write_b32 a250, 0\n\t"
+      "v_accvgpr_write_b32 a251, 0\n\t"
+      "v_accvgpr_write_b32 a252, 0\n\t"
+      "v_accvgpr_write_b32 a253, 0\n\t"
+      "v_accvgpr_write_b32 a254, 0\n\t"
+      "v_accvgpr_write_b32 a255, 0\n\t"
+      ""
+      :
+      :
+      : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
+// every asm MFMA issued so far has written its accumulator (8-pass XDL write -> v_accvgpr_read: 18 wait states cover it)
+__device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+
 // rescale threshold of both kernels, exp2 domain (probabilities reach at most 2^PF_THR; 0 = the textbook rule)
 #ifndef PF_THR
 #define PF_THR 8
@@ -420,25 +587,113 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// First exp micro-op (of 112: see `micro` in the kernel) of MFMA slot k of a unit: ops are dealt in order, a slot takes
-// ops while their issue costs (fma / add / pack 4 cycles, exp2 8) fit P4_CAP; everything is placed by slot 24, where the
-// second half of P is first needed.
+// P4_PRESCALE (A/B builds only, default 0 = exact): Q pre-multiplied by sm_scale * log2(e) and rounded to the model dtype,
+// the QK^T chains seeded with minus the running max - a logit then needs no VALU instruction before its exp2 (-32 of
+// ~190 VALU instructions per 32-key unit).  NOT the shipped path: the extra rounding of q * c moves a logit by
+// |logit| * 2^-9 / sqrt(3) (bf16) in the worst case, which breaks the reference's own tolerance on large-logit inputs
+// (tests/test_gpu_prefill.py::test_prefill_deterministic_and_large_logits: 1.0e-2 against 3e-3 in fp16); measured gain
+// in DESIGN.md section 3.2.
+#ifndef P4_PRESCALE
+#define P4_PRESCALE 0
+#endif
+#if P4_PRESCALE
+// Exp work of a unit = 80 micro-ops (see `micro` in the kernel): item j (two logits of one query block) is exp2, exp2,
+// then - one item late - row-sum add, add, pack.  First micro-op of MFMA slot k: ops are dealt in order, a slot takes ops
+// while their issue costs (exp2 8 cycles, add / pack 4) fit P4_CAP; everything is placed by slot 24, where the second
+// half of P is first needed.
+constexpr int P4_NOPS = 80;
+__host__ __device__ constexpr int p4_op_cost(int g) {
+  if (g < 2) return 8;
+  const int t = g - 2, b = 1 + t / 5, r = t % 5;
+  return (b < 16 && r < 2) ? 8 : 4;
+}
 __host__ __device__ constexpr int p4_mb(int k) {
   int g = 0;
   for (int slot = 0; slot < k && slot < 24; ++slot) {
     int used = 0;
-    while (g < 112) {
-      const int op = g < 4 ? g : ((g - 4) / 7 == 15 ? 4 + (g - 4) % 7 : (g - 4) % 7);
-      const int cost = (op == 2 || op == 3) ? 8 : 4;
+    while (g < P4_NOPS) {
+      const int cost = p4_op_cost(g);
       if (used + cost > P4_CAP && slot != 23) break;
       used += cost;
       ++g;
     }
   }
-  return k >= 24 ? 112 : g;
+  return k >= 24 ? P4_NOPS : g;
 }
-static_assert(p4_mb(0) == 0 && p4_mb(24) == 112, "exp micro-op placement");
-static_assert(p4_mb(16) >= 4 + 7 * 7 + 7, "P of keys 0-15 must be complete before the first PV MFMA");
+static_assert(p4_mb(0) == 0 && p4_mb(24) == P4_NOPS, "exp micro-op placement");
+static_assert(p4_mb(15) >= 2 + 5 * 3 + 5 && p4_mb(16) >= 2 + 5 * 7 + 5 && p4_mb(23) >= 2 + 5 * 11 + 5,
+              "every group of packed words complete one slot before its first PV MFMA (see the exact variant)");
+#else
+// Exp work of a unit = 112 micro-ops (see `micro` in the kernel).  Item j (two logits of one query block): fma, fma (the
+// logits into the exp2 domain, minus the running max), exp2, exp2, row-sum add, add, pack.  Stream order: item 0's fma,
+// fma, exp2, exp2; then for b = 1..15: fma, fma of item b, add, add, pack of item b-1, exp2, exp2 of item b; then add,
+// add, pack of item 15 - an exp2 never directly follows the fma that feeds it and an add never directly follows the exp2
+// it consumes (hipcc otherwise pads those pairs with s_nop: 15 issue slots per unit in the first ordering).
+// First micro-op of MFMA slot k: ops are dealt in order, a slot takes ops while their issue costs (exp2 8 cycles, the
+// others 4) fit P4_CAP; everything is placed by slot 24, where the second half of P is first needed.
+// P4_MFMA_ROWSUM (A/B builds only, default 0): the row sums l from one extra MFMA per (query block, 16 keys) - an all-ones
+// A operand times the packed P fragment the PV MFMAs consume anyway - instead of 32 v_add_f32 per unit: +4 MFMAs for -32
+// VALU instructions per unit.  MEASURED SLOWER (7.89 ms against 7.56 ms at 32 K on one box, profiles/r03_prefill_ab.txt):
+// the stream is in-order, an MFMA issued behind another waits out the matrix pipe, and the 8 extra MFMAs per tile cost
+// more than the 64 adds they replace.  (It would also sum the probabilities as ROUNDED to the model dtype, where the
+// reference adds the fp32 values, :398-400.)
+#ifndef P4_MFMA_ROWSUM
+#define P4_MFMA_ROWSUM 0
+#endif
+#if P4_MFMA_ROWSUM
+constexpr int P4_NOPS = 80;  // item: fma, fma, exp2, exp2, pack; stream: F F E E (item 0), then F F P' E E per item, P' last
+__host__ __device__ constexpr int p4_op_kind(int g) {  // 0,1 fma  2,3 exp2  6 pack
+  if (g < 4) return g;
+  const int t = g - 4, b = 1 + t / 5, r = t % 5;
+  if (b == 16) return 6;
+  return r < 2 ? r : (r == 2 ? 6 : r - 1);
+}
+__host__ __device__ constexpr int p4_op_item(int g) {
+  if (g < 4) return 0;
+  const int t = g - 4, b = 1 + t / 5, r = t % 5;
+  if (b == 16) return 15;
+  return r == 2 ? b - 1 : b;
+}
+constexpr int P4_PACK_IDX(int item) { return 4 + 5 * item + 2; }  // stream index of item's pack
+#else
+constexpr int P4_NOPS = 112;
+__host__ __device__ constexpr int p4_op_kind(int g) {  // 0,1 fma  2,3 exp2  4,5 add  6 pack
+  if (g < 4) return g;
+  const int t = g - 4, b = 1 + t / 7, r = t % 7;
+  if (b == 16) return 4 + r;
+  return r < 2 ? r : (r < 5 ? r + 2 : r - 3);
+}
+__host__ __device__ constexpr int p4_op_item(int g) {
+  if (g < 4) return 0;
+  const int t = g - 4, b = 1 + t / 7, r = t % 7;
+  if (b == 16) return 15;
+  return (r >= 2 && r <= 4) ? b - 1 : b;
+}
+constexpr int P4_PACK_IDX(int item) { return 4 + 7 * item + 4; }
+#endif
+__host__ __device__ constexpr int p4_mb(int k) {
+  int g = 0;
+  for (int slot = 0; slot < k && slot < 24; ++slot) {
+    int used = 0;
+    while (g < P4_NOPS) {
+      const int kind = p4_op_kind(g);
+      const int cost = (kind == 2 || kind == 3) ? 8 : 4;
+      if (used + cost > P4_CAP && slot != 23) break;
+      used += cost;
+      ++g;
+    }
+  }
+  return k >= 24 ? P4_NOPS : g;
+}
+static_assert(p4_mb(0) == 0 && p4_mb(24) == P4_NOPS, "exp micro-op placement");
+// The PV MFMAs are inline asm (pv_mfma): hipcc pads no VALU-write -> MFMA-read hazard for them, the placement does.  Slot
+// 16 + kk reads the packed words of query block kk & 1: items 0-3 / 4-7 (keys 0-15) from slot 16 / 17, items 8-11 / 12-15
+// (keys 16-31) from slot 24 / 25.  Each group's last pack must sit at least one whole slot (an MFMA and its fillers)
+// before its first reader:
+static_assert(p4_mb(15) > P4_PACK_IDX(3), "P of items 0-3 complete before slot 15 ends");
+static_assert(p4_mb(16) > P4_PACK_IDX(7), "P of items 4-7 complete before slot 16 ends");
+static_assert(p4_mb(23) > P4_PACK_IDX(11), "P of items 8-11 complete before slot 23 ends");
+#endif
 // -DCVLLM_PF_TS (debug builds of tools/dbg only): s_memrealtime at the phase boundaries of every workgroup
 #ifdef CVLLM_PF_TS
 __device__ unsigned long long g_pf_rt[8192 * 8];  // [workgroup][4 x s_memrealtime (100 MHz) | 4 x s_memtime (shader clock)]
@@ -506,6 +761,18 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
+#if P4_PRESCALE
+      // Q is pre-scaled by sm_scale * log2(e) ONCE (fp32 product rounded to the model dtype): the QK^T MFMAs then
+      // deliver the logits in the exp2 domain and - started from an accumulator that holds minus the running max, see
+      // `negm` - already relative to it, so a logit costs no VALU instruction before its exp2 (the reference scales the
+      // fp32 logit, sparse_varlen_kernel.py:360,385-392: the rounding of q * c to 16 bits moves a logit by ~1e-3 in the
+      // exp2 domain for bf16, below the rounding of P itself; the parity tests hold the reference's own tolerance).
+      const float2 a0 = unpack2<T>(t.x), a1 = unpack2<T>(t.y), a2 = unpack2<T>(t.z), a3 = unpack2<T>(t.w);
+      t.x = pack2<T>(a0.x * scale_log2e, a0.y * scale_log2e);
+      t.y = pack2<T>(a1.x * scale_log2e, a1.y * scale_log2e);
+      t.z = pack2<T>(a2.x * scale_log2e, a2.y * scale_log2e);
+      t.w = pack2<T>(a3.x * scale_log2e, a3.y * scale_log2e);
+#endif
       qf[qb][s] = __builtin_bit_cast(s16x8, t);
     }
   }
@@ -516,15 +783,29 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   const int ntiles = ntc + nta;
 
   // ---- accumulators and LDS addressing ------------------------------------------------------------------------------
-  f32x16 oacc[2][DB];
+  acc_zero_all();  // O^T accumulators a[128:255] (see pv_mfma): block (qb, db) = a[128 + 16 (4 qb + db) .. + 15]
+#if P4_PRESCALE
+  // minus the running max (exp2 domain) of this lane's query, in all 16 registers of a block: the C operand every
+  // S = K Q^T chain starts from, so the chain ends in s*c - m (the attention-backward trick of the CDNA guide: row
+  // constants as the initial accumulator).  Rewritten only when a row's running max moves (rare, deferred rescale).
+  f32x16 negm[2];
+#else
+  float m_run[2] = {-1e30f, -1e30f};  // running max (exp2 domain), identical in lanes l and l^32; finite (see chain)
+#endif
+  // running sums of this lane's half of the keys, two per query block (even / odd logits of an item: consecutive adds
+  // never depend on each other); the probabilities are added straight into them
+  float l_run[2] = {0.f, 0.f}, l_run2[2] = {0.f, 0.f};
+#if P4_MFMA_ROWSUM && !P4_PRESCALE
+  // row sums by MFMA: D = ones(32 x 16) * P^T fragment + D puts a query's sum over the fragment's 16 keys (both lane
+  // halves) into every row of its column; only element 0 of a block is ever read (the rows never mix)
+  f32x16 lsum[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) oacc[qb][db][i] = 0.f;
-  float m_run[2] = {-1e30f, -1e30f};  // running max (exp2 domain), identical in lanes l and l^32; finite (see chain)
-  float l_run[2] = {0.f, 0.f};        // running sum of this lane's half of the keys
+    for (int i = 0; i < 16; ++i) lsum[qb][i] = 0.f;
+  const uint32_t one2 = pack2<T>(1.f, 1.f);
+  const s16x8 ones = __builtin_bit_cast(s16x8, make_uint4(one2, one2, one2, one2));
+#endif
 
   const int gi = lane >> 4;
   const int li = lane & 15;
@@ -547,12 +828,18 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   int ld_pi = 0, ld_po = 0;
   int ld_pg = (ntc > 0) ? pt[0] : 0;
   // The bounds check of a buffer load covers the VGPR offset only (not the scalar offset), so the row offset lives
-  // in the VGPR - four loop-invariant offsets per tensor, rebuilt once when the tiles change from cached to appended -
-  // and the tile's base and valid byte count in the descriptor.  The two kinds are separate (uniform) branches: with
-  // one wave per SIMD every instruction of any kind takes an issue slot from the MFMAs, and selecting between two
-  // 64-bit address computations per tile cost 80 scalar instructions.
-  uint32_t voffk[4], voffv[4];
-  int voff_kind = -1;  // 0 = cached layout, 1 = appended layout
+  // in the VGPR - four loop-invariant offsets per layout (cached rows are D elements apart, appended rows sk_n / sv_n),
+  // all three sets live for the whole kernel (the output accumulators sit in AGPRs, arch VGPRs are plentiful) and ONE
+  // v_cndmask per load picks the tile's layout (keeping a "current" set that is rewritten at the cached -> appended
+  // change made hipcc copy a set in every tile: 16-33 v_mov) - and the tile's base and valid byte count in the descriptor.
+  uint32_t voffc[4], voffak[4], voffav[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    voffc[i] = (uint32_t)(srow + 16 * i) * (D * 2) + sch * 16;
+    voffak[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sk_n * 2 + sch * 16;
+    voffav[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sv_n * 2 + sch * 16;
+  }
+  bool ld_app = false;  // layout of the tile whose descriptors are current (workgroup-uniform)
   __amdgpu_buffer_rsrc_t rk, rv;
   // running state of the two kinds: the current page's base (cached) / the next tile's base and the valid bytes from
   // there to the end of the visible rows (appended) - a tile costs two 64-bit adds and a subtract, not a 64-bit multiply
@@ -564,12 +851,8 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   int a_remv = la_vis > 0 ? (int)(((uint32_t)(la_vis - 1) * (uint32_t)sv_n + D) * 2) : 0;
   const int a_stepk = PF_KT * (int)sk_n, a_stepv = PF_KT * (int)sv_n;  // elements per appended tile
   auto tile_desc = [&](int tt) __attribute__((always_inline)) {
-    if (tt < ntc) {
-      if (voff_kind != 0) {
-        voff_kind = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) voffk[i] = voffv[i] = (uint32_t)(srow + 16 * i) * (D * 2) + sch * 16;
-      }
+    ld_app = tt >= ntc;
+    if (!ld_app) {
       const int count = min(PF_KT, Lc - tt * PF_KT);  // > 0
       rk = __builtin_amdgcn_make_buffer_rsrc((void*)(c_kp + ld_po * D), 0, count * D * 2, 0x00020000);
       rv = __builtin_amdgcn_make_buffer_rsrc((void*)(c_vp + ld_po * D), 0, count * D * 2, 0x00020000);
@@ -582,14 +865,6 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         c_vp = vc + (int64_t)ld_pg * PS * D;
       }
     } else {
-      if (voff_kind != 1) {
-        voff_kind = 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          voffk[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sk_n * 2 + sch * 16;
-          voffv[i] = (uint32_t)(srow + 16 * i) * (uint32_t)sv_n * 2 + sch * 16;
-        }
-      }
       // valid bytes reach to the END of the visible rows (the four row offsets cover 64 rows anyway); tiles past the
       // last one have nothing left: every row out of range, nothing is fetched
       rk = __builtin_amdgcn_make_buffer_rsrc((void*)a_kp, 0, max(a_remk, 0), 0x00020000);
@@ -601,8 +876,8 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   };
   auto gload_piece = [&](int set, int i) __attribute__((always_inline)) {
-    st[set][i] = (i < 4) ? __builtin_amdgcn_raw_buffer_load_b128(rk, voffk[i & 3], 0, 0)
-                         : __builtin_amdgcn_raw_buffer_load_b128(rv, voffv[i & 3], 0, 0);
+    st[set][i] = (i < 4) ? __builtin_amdgcn_raw_buffer_load_b128(rk, ld_app ? voffak[i & 3] : voffc[i & 3], 0, 0)
+                         : __builtin_amdgcn_raw_buffer_load_b128(rv, ld_app ? voffav[i & 3] : voffc[i & 3], 0, 0);
   };
   const uint32_t kst = srow * PF_KSTR + sch * 16, vst = srow * PF_VSTR + sch * 16;
   auto lstore_piece = [&](int set, int buf, int i) __attribute__((always_inline)) {
@@ -649,20 +924,48 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     return (const lds_char*)(uintptr_t)va;
   };
 
-  float psum[2] = {0.f, 0.f}, mx_raw[2] = {-INFINITY, -INFINITY}, mx_new[2] = {0.f, 0.f};
+  float mx_raw[2] = {-INFINITY, -INFINITY}, mx_new[2] = {0.f, 0.f};
   u32x4 pw[2][2];   // P fragments of the current unit [query block][keys 0-15 / 16-31]
   s16x8 kfr[4], vfr[4];  // fragment rings: reads run three fragments ahead of their MFMAs
 
-  // The exp work of a unit as a list of 112 micro-ops, dealt to the unit's first 24 MFMA shadows by issue
-  // cost (p4_mb below).  Item j = 8 s2 + 4 qb + jp turns two logits into two probabilities and one packed word:
-  // ops 0-3 (fma, fma, exp2, exp2) of item b, then ops 4-6 (row-sum add, add, pack) of item b-1 - the adds one item
-  // late, or they would wait out the transcendental unit's latency.  Every op ends in an empty asm anchor: hipcc's
-  // IR passes otherwise sink it to its first use (the PV MFMA, the l update), out of its slot.
+#if P4_PRESCALE
+  // The exp work of a unit as a list of 80 micro-ops, dealt to the unit's first 24 MFMA shadows by issue cost
+  // (p4_mb above).  Item j = 8 s2 + 4 qb + jp turns two logits (already s*c - m) into two probabilities and one packed
+  // word: ops 0-1 (exp2, exp2) of item b, then ops 2-4 (row-sum add, add, pack) of item b-1 - the adds one item late,
+  // or they would wait out the transcendental unit's latency.  Every op ends in an empty asm anchor: hipcc's IR passes
+  // otherwise sink it to its first use (the PV MFMA, the l update), out of its slot.
+  float mp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  auto micro = [&](const f32x16(&sc_)[2], int g) __attribute__((always_inline)) {
+    const int b = g < 2 ? 0 : 1 + (g - 2) / 5;
+    const int op = g < 2 ? g : (b == 16 ? 2 + (g - 2) % 5 : (g - 2) % 5);
+    const int j = op < 2 ? b : b - 1;
+    const int s2 = j >> 3, qb = (j >> 2) & 1, jp = j & 3;
+    if (op == 0) {
+      mp[j & 1][0] = __builtin_amdgcn_exp2f(sc_[qb][8 * s2 + 2 * jp]);
+      asm volatile("" : "+v"(mp[j & 1][0]));
+    } else if (op == 1) {
+      mp[j & 1][1] = __builtin_amdgcn_exp2f(sc_[qb][8 * s2 + 2 * jp + 1]);
+      asm volatile("" : "+v"(mp[j & 1][1]));
+    } else if (op == 2) {
+      l_run[qb] += mp[j & 1][0];  // the row sum is taken from the fp32 probabilities ...
+      asm volatile("" : "+v"(l_run[qb]));
+    } else if (op == 3) {
+      l_run2[qb] += mp[j & 1][1];
+      asm volatile("" : "+v"(l_run2[qb]));
+    } else {
+      uint32_t w = pack2<T>(mp[j & 1][0], mp[j & 1][1]);  // ... P itself is rounded to the model dtype (reference :398-400)
+      asm volatile("" : "+v"(w));
+      pw[qb][s2][jp] = w;
+    }
+  };
+#else
+  // The exp work of a unit as the list of 112 micro-ops described at p4_op_kind, dealt to the unit's first 24 MFMA
+  // shadows by issue cost (p4_mb).  Item j = 8 s2 + 4 qb + jp turns two logits into two probabilities and one packed
+  // word.  Every op ends in an empty asm anchor: hipcc's IR passes otherwise sink it to its first use (the PV MFMA, the l
+  // update), out of its slot.
   float me0 = 0.f, me1 = 0.f, mp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
   auto micro = [&](const f32x16(&sc_)[2], int g) __attribute__((always_inline)) {
-    const int b = g < 4 ? 0 : 1 + (g - 4) / 7;
-    const int op = g < 4 ? g : (b == 16 ? 4 + (g - 4) % 7 : (g - 4) % 7);
-    const int j = op < 4 ? b : b - 1;
+    const int op = p4_op_kind(g), j = p4_op_item(g);
     const int s2 = j >> 3, qb = (j >> 2) & 1, jp = j & 3;
     if (op == 0) {
       me0 = fmaf(sc_[qb][8 * s2 + 2 * jp], scale_log2e, -m_run[qb]);
@@ -677,32 +980,51 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       mp[j & 1][1] = __builtin_amdgcn_exp2f(me1);
       asm volatile("" : "+v"(mp[j & 1][1]));
     } else if (op == 4) {
-      psum[qb] += mp[j & 1][0];  // the row sum is taken from the fp32 probabilities ...
-      asm volatile("" : "+v"(psum[qb]));
+      l_run[qb] += mp[j & 1][0];  // (P4_MFMA_ROWSUM = 0) the row sum is taken from the fp32 probabilities ...
+      asm volatile("" : "+v"(l_run[qb]));
     } else if (op == 5) {
-      psum[qb] += mp[j & 1][1];
-      asm volatile("" : "+v"(psum[qb]));
+      l_run2[qb] += mp[j & 1][1];
+      asm volatile("" : "+v"(l_run2[qb]));
     } else {
       uint32_t w = pack2<T>(mp[j & 1][0], mp[j & 1][1]);  // ... P itself is rounded to the model dtype (reference :398-400)
       asm volatile("" : "+v"(w));
       pw[qb][s2][jp] = w;
     }
   };
-  // row max of S over a 32-key block in three parts (part 2 ends with the partner-lane exchange)
-  float mxa = 0.f, mxb = 0.f;
-  auto max_part = [&](const f32x16& a, int part, float& out) __attribute__((always_inline)) {
+#endif
+  // row max of S over a 32-key block in four parts: three of max3 work, then the partner-lane exchange (its own part, a
+  // slot later: v_permlane32_swap needs its two source registers written two wait states earlier, and the copy that
+  // makes the second one sits at the end of part 2 - placed back to back hipcc pads them with s_nop 1)
+  float mxa = 0.f, mxb = 0.f, mxc[2] = {0.f, 0.f}, mxd[2] = {0.f, 0.f};
+  auto max_part = [&](const f32x16& a, int part, int qbi, float& out) __attribute__((always_inline)) {
     if (part == 0) {
       mxa = max3(a[0], a[1], a[2]), mxb = max3(a[3], a[4], a[5]);
       mxa = max3(mxa, a[6], a[7]);
     } else if (part == 1) {
       mxb = max3(mxb, a[8], a[9]);
       mxa = max3(mxa, a[10], a[11]), mxb = max3(mxb, a[12], a[13]);
+    } else if (part == 2) {
+      mxc[qbi] = max3(mxa, mxb, fmaxf(a[14], a[15]));
+      mxd[qbi] = mxc[qbi];
+      asm volatile("" : "+v"(mxc[qbi]), "+v"(mxd[qbi]));  // two registers, now
     } else {
-      const float mx = max3(mxa, mxb, fmaxf(a[14], a[15]));
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxc[qbi]), __float_as_uint(mxd[qbi]), false, false);
       out = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
   };
+#if P4_PRESCALE
+  // running-max bookkeeping of the NEXT unit for one query block: its logits are already relative to the running max,
+  // so their row max (mx_raw) IS the growth of the max.
+  // Deferred rescale (MI355X guide T13): the running max follows the row max only once it has grown by more than
+  // PF_THR in the exp2 domain, so probabilities reach at most 2^PF_THR instead of 1 - bf16 / fp16 keep their relative
+  // precision there and the fp32 sums have the headroom - and the 128-register rescale of O becomes rare (with an
+  // exact running max some row of a wave grows in every 5th unit of random data).  Every quantity at the old scale
+  // (O, l, the accumulator seed negm AND the next unit's logits, which were computed from the old seed; no P is pending
+  // at the decision) is moved exactly once.  PF_THR = 0 is the textbook rule.
+  auto chain = [&](int qb) __attribute__((always_inline)) { mx_new[qb] = mx_raw[qb]; };
+  // mask of unit (t, kb), rare: key kk of the unit is visible to this lane's query iff kk < lim.  Branch-free integer
+  // form (sign mask): a compare per logit would put dozens of lane masks into SGPR pairs at once.
+#else
   // running-max bookkeeping of the NEXT unit for one query block (its logits' row max is in mx_raw).
   // Deferred rescale (MI355X guide T13): the running max follows the row max only once it has grown by more than
   // PF_THR in the exp2 domain, so probabilities reach at most 2^PF_THR instead of 1 - bf16 / fp16 keep their relative
@@ -712,13 +1034,14 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   // max starts at a large negative FINITE value: no -inf special case on the common path (3 VALU per query block and
   // unit), a row's first visible key always takes, and exp2(-inf c + 1e30) of a masked logit is still 0.
   auto chain = [&](int qb) __attribute__((always_inline)) { mx_new[qb] = mx_raw[qb] * scale_log2e; };
-  // mask of unit (t, kb), rare: key kk of the unit is visible to this lane's query iff kk < lim.  Branch-free integer
-  // form (sign mask): a compare per logit would put dozens of lane masks into SGPR pairs at once.
+#endif
+  // Which 32-key units need the mask (workgroup-uniform), as two scalar thresholds on the unit index u = 2 t + kb:
+  // cached units from the first one that is not full (u >= Lc / 32) and appended units from the first one that reaches
+  // past the tile's first query (32 ua + 31 > m0  <=>  ua >= (m0 + 1) / 32; a short last unit lies behind that one).
+  const int u_cmask = Lc / 32, u_cend = 2 * ntc, u_amask = 2 * ntc + (m0 + 1) / 32;
   auto unit_needs_mask = [&](int t, int kb) __attribute__((always_inline)) {
-    const bool cached = t < ntc;
-    const int j0 = (cached ? t * PF_KT : (t - ntc) * PF_KT) + 32 * kb;
-    const int count = (cached ? Lc : la_vis) - j0;
-    return count < 32 || (!cached && j0 + 31 > m0);  // workgroup-uniform
+    const int u = 2 * t + kb;
+    return (u >= u_cmask && u < u_cend) || u >= u_amask;
   };
   auto unit_mask = [&](int t, int kb, f32x16(&sc_)[2]) __attribute__((always_inline)) {
     const bool cached = t < ntc;
@@ -735,24 +1058,73 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       }
     }
   };
-  auto rescale_if_grew = [&]() __attribute__((always_inline)) {
+#if P4_PRESCALE
+  auto rescale_if_grew = [&](f32x16(&sn_)[2]) __attribute__((always_inline)) {
+    // a fully masked unit has mx_new = -inf: never taken
+    const bool t0 = mx_new[0] > (float)PF_THR, t1 = mx_new[1] > (float)PF_THR;
+    if (__builtin_amdgcn_ballot_w64(t0 || t1) != 0) {  // rare: some row of the wave moves its running max
+      acc_settle();
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const bool take = qb ? t1 : t0;
+        const float dm = take ? mx_new[qb] : 0.f;  // the running max grows by dm
+        const float alpha = __builtin_amdgcn_exp2f(-dm);
+        l_run[qb] *= alpha;
+        l_run2[qb] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          negm[qb][i] -= dm;
+          sn_[qb][i] -= dm;
+        }
+        if (qb == 0)
+          static_for<0, 64>([&](auto r_c) __attribute__((always_inline)) {
+            constexpr int R = P4_ACC0 + decltype(r_c)::value;
+            acc_write<R>(acc_read<R>() * alpha);
+          });
+        else
+          static_for<64, 128>([&](auto r_c) __attribute__((always_inline)) {
+            constexpr int R = P4_ACC0 + decltype(r_c)::value;
+            acc_write<R>(acc_read<R>() * alpha);
+          });
+      }
+      // the rewritten accumulators / seeds are MFMA operands next: VALU / v_accvgpr_write -> MFMA wait states
+      asm volatile("s_nop 3" ::: "memory");
+    }
+  };
+
+#else
+  auto rescale_if_grew = [&](f32x16(&)[2]) __attribute__((always_inline)) {
     // a fully masked unit has mx_new = -inf: never taken
     const bool t0 = mx_new[0] - m_run[0] > (float)PF_THR, t1 = mx_new[1] - m_run[1] > (float)PF_THR;
-    if (__builtin_amdgcn_ballot_w64(t0 || t1) != 0) {  // rare: some row of the wave moves its running max
+    if ((__builtin_amdgcn_ballot_w64(t0) | __builtin_amdgcn_ballot_w64(t1)) != 0) {  // rare: a row moves its running max
+      acc_settle();
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const bool take = qb ? t1 : t0;
         const float alpha = take ? __builtin_amdgcn_exp2f(m_run[qb] - mx_new[qb]) : 1.f;
         m_run[qb] = take ? mx_new[qb] : m_run[qb];
+#if P4_MFMA_ROWSUM
+        lsum[qb][0] *= alpha;
+#else
         l_run[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) oacc[qb][db][i] *= alpha;
+        l_run2[qb] *= alpha;
+#endif
+        if (qb == 0)
+          static_for<0, 64>([&](auto r_c) __attribute__((always_inline)) {
+            constexpr int R = P4_ACC0 + decltype(r_c)::value;
+            acc_write<R>(acc_read<R>() * alpha);
+          });
+        else
+          static_for<64, 128>([&](auto r_c) __attribute__((always_inline)) {
+            constexpr int R = P4_ACC0 + decltype(r_c)::value;
+            acc_write<R>(acc_read<R>() * alpha);
+          });
       }
+      asm volatile("s_nop 3" ::: "memory");  // v_accvgpr_write -> MFMA reads the register as its accumulator
     }
   };
 
+#endif
   // phase A of a unit: S(next) = K[next unit] Q^T beside the first ITEMS_A exp items of the current unit.
   // Entry: kfr[0..2] hold k-steps 0-2 of the next unit's K block.  Exit: vfr[0..2] hold this unit's first V fragments.
   auto phase_a = [&](const lds_char* kbp, const lds_char* vbp, const f32x16(&sc_)[2], f32x16(&sn_)[2], auto extra)
@@ -762,10 +1134,14 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       constexpr int s = kk >> 1, qb = kk & 1;
       if (qb == 0 && s + 3 < KS) kfr[(s + 3) % 4] = k_read(kbp, s + 3);
       if (s == 0) {
+#if P4_PRESCALE
+        sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], negm[qb]);  // the chain starts at minus the running max
+#else
         f32x16 z;
 #pragma unroll
         for (int i = 0; i < 16; ++i) z[i] = 0.f;
         sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], z);
+#endif
       } else {
         sn_[qb] = mfma32<T>(kfr[s % 4], qf[qb][s], sn_[qb]);
       }
@@ -786,35 +1162,42 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       constexpr int kk = decltype(kk_c)::value;
       constexpr int i = kk >> 1, qb = kk & 1;
       if (qb == 0) vfr[(i + 3) % 4] = v_read(vbp, i + 3);
-      oacc[qb][i & 3] = mfma32<T>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][0]), oacc[qb][i & 3]);
+      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][0]));
+#if P4_MFMA_ROWSUM && !P4_PRESCALE
+      if constexpr (kk < 2) lsum[qb] = mfma32<T>(ones, __builtin_bit_cast(s16x8, pw[qb][0]), lsum[qb]);
+#endif
       static_for<p4_mb(16 + kk), p4_mb(16 + kk + 1)>(
           [&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
-      if (kk == 7) {
-        l_run[0] += psum[0];
-        l_run[1] += psum[1];
-        psum[0] = psum[1] = 0.f;
-      }
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
     if (unit_needs_mask(tn, kbn)) unit_mask(tn, kbn, sn_);
-#pragma unroll
-    for (int kk = 8; kk < 16; ++kk) {
-      const int i = kk >> 1, qb = kk & 1;
+    static_for<8, 16>([&](auto kk_c) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value;
+      constexpr int i = kk >> 1, qb = kk & 1;
       if (qb == 0 && i + 3 < 8) vfr[(i + 3) % 4] = v_read(vbp, i + 3);
-      oacc[qb][i & 3] = mfma32<T>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][1]), oacc[qb][i & 3]);
-      if (kk < 14) max_part(sn_[(kk - 8) / 3], (kk - 8) % 3, mx_raw[(kk - 8) / 3]);
-      if (kk == 11) kfr[0] = k_read(kbp_next, 0);
+      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][1]));
+#if P4_MFMA_ROWSUM && !P4_PRESCALE
+      if constexpr (kk < 10) lsum[qb] = mfma32<T>(ones, __builtin_bit_cast(s16x8, pw[qb][1]), lsum[qb]);
+#endif
+      if constexpr (kk < 14) max_part(sn_[(kk - 8) / 3], (kk - 8) % 3, (kk - 8) / 3, mx_raw[(kk - 8) / 3]);
+      if (kk == 11) {
+        max_part(sn_[0], 3, 0, mx_raw[0]);  // exchange of query block 0, one slot after its part 2
+        kfr[0] = k_read(kbp_next, 0);
+      }
       if (kk == 13) kfr[1] = k_read(kbp_next, 1);
-      if (kk == 14) chain(0);
+      if (kk == 14) {
+        max_part(sn_[1], 3, 1, mx_raw[1]);
+        chain(0);
+      }
       if (kk == 15) {
         chain(1);
         kfr[2] = k_read(kbp_next, 2);
       }
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    rescale_if_grew();
+    });
+    rescale_if_grew(sn_);
   };
   auto no_extra = [](int) {};
 
@@ -846,10 +1229,24 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
     if (unit_needs_mask(0, 0)) unit_mask(0, 0, sX);
 #pragma unroll
-    for (int part = 0; part < 6; ++part) max_part(sX[part / 3], part % 3, mx_raw[part / 3]);
+    for (int part = 0; part < 8; ++part) max_part(sX[part / 4], part % 4, part / 4, mx_raw[part / 4]);
+#if P4_PRESCALE
+    // the first unit's row max IS the initial running max (O and l are still zero: nothing to rescale); every query
+    // sees at least one key of its first unit, a row without one (never stored) starts at 0
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float m_first = mx_raw[qb] == -INFINITY ? 0.f : mx_raw[qb];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        negm[qb][i] = -m_first;
+        sX[qb][i] -= m_first;
+      }
+    }
+#else
     chain(0);
     chain(1);
-    rescale_if_grew();  // O and l are still zero: this only moves the running max
+    rescale_if_grew(sX);  // O and l are still zero: this only moves the running max
+#endif
     const lds_char* kb1 = k_ptr(0, 1);
     kfr[0] = k_read(kb1, 0);
     kfr[1] = k_read(kb1, 1);
@@ -905,22 +1302,26 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   PF_RT(2);
 
   // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ---------------------------
+  acc_settle();
   char* ob = smem + wave * (64 * PF_OSTRIDE);
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+  static_for<0, 2>([&](auto qb_c) __attribute__((always_inline)) {
+    constexpr int qb = decltype(qb_c)::value;
+#if P4_MFMA_ROWSUM && !P4_PRESCALE
+    const float l_tot = lsum[qb][0];  // the MFMA already summed both lane halves' keys
+#else
+    const float l_lane = l_run[qb] + l_run2[qb];
+    const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
+#endif
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-#pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) {
-        const int d = db * 32 + 8 * i4 + 4 * h;
-        const uint32_t w0 = pack2<T>(oacc[qb][db][4 * i4] * inv, oacc[qb][db][4 * i4 + 1] * inv);
-        const uint32_t w1 = pack2<T>(oacc[qb][db][4 * i4 + 2] * inv, oacc[qb][db][4 * i4 + 3] * inv);
-        *reinterpret_cast<uint2*>(ob + (qb * 32 + r) * PF_OSTRIDE + d * 2) = make_uint2(w0, w1);
-      }
-    }
-  }
+    static_for<0, 16>([&](auto j_c) __attribute__((always_inline)) {
+      constexpr int db = decltype(j_c)::value >> 2, i4 = decltype(j_c)::value & 3;
+      constexpr int R = P4_ACC0 + 16 * (4 * qb + db) + 4 * i4;
+      const int d = db * 32 + 8 * i4 + 4 * h;
+      const uint32_t w0 = pack2<T>(acc_read<R>() * inv, acc_read<R + 1>() * inv);
+      const uint32_t w1 = pack2<T>(acc_read<R + 2>() * inv, acc_read<R + 3>() * inv);
+      *reinterpret_cast<uint2*>(ob + (qb * 32 + r) * PF_OSTRIDE + d * 2) = make_uint2(w0, w1);
+    });
+  });
   // the wave re-reads only what it wrote itself: LDS ops of one wave execute in order, no barrier needed
 #pragma unroll
   for (int it = 0; it < 16; ++it) {

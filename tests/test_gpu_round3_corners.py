@@ -135,7 +135,10 @@ def test_select_lookback_timeout_raises_status_not_trap(dev):
     assert written.numel() > 0 and int(written.min()) >= 0 and int(written.max()) < L
     # the product path still works in the same process afterwards (no context loss)
     kept2, lens2 = select_retained(scores, cu, L, retain, bm, l0, PS, True)
-    assert torch.equal(kept2, kept_ok) and torch.equal(lens2, lens_ok) and select_status() == 0
+    assert torch.equal(lens2, lens_ok) and select_status() == 0
+    for h in range(H):  # entries beyond a head's count are unspecified (torch.empty)
+        n = int(lens_ok[0, h])
+        assert torch.equal(kept2[0, h, :n], kept_ok[0, h, :n])
 
 
 def test_decode_merge_modes_and_status_over_all_workspaces(dev):
@@ -149,15 +152,16 @@ def test_decode_merge_modes_and_status_over_all_workspaces(dev):
     kc, vc, pt, bm, P = mk_paged(B, HKV, D, PS, lens, torch.bfloat16, seed=3)
     q = torch.randn(B, HQ, D).to(torch.bfloat16)
     args = (kc.to(dev), vc.to(dev), lens.to(dev), pt.to(dev), bm.to(dev), HKV, PS)
-    out = dk.head_sparse_decode_attention(q.to(dev), *args)
+    qd = q.to(dev)
+    out = dk.head_sparse_decode_attention(qd, *args)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        dk.head_sparse_decode_attention(q.to(dev), *args)  # allocates the side stream's workspace
+        dk.head_sparse_decode_attention(qd, *args)  # allocates the side stream's workspace
         side.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            out_g = dk.head_sparse_decode_attention(q.to(dev), *args)
+            out_g = dk.head_sparse_decode_attention(qd, *args)
     g.replay()
     torch.cuda.synchronize()
     ref = O.decode_attention(q, kc, vc, lens, pt, bm, HKV, PS, 1.0 / D ** 0.5)
