@@ -1039,10 +1039,10 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   // cached units from the first one that is not full (u >= Lc / 32) and appended units from the first one that reaches
   // past the tile's first query (32 ua + 31 > m0  <=>  ua >= (m0 + 1) / 32; a short last unit lies behind that one).
   const int u_cmask = Lc / 32, u_cend = 2 * ntc, u_amask = 2 * ntc + (m0 + 1) / 32;
-  auto unit_needs_mask = [&](int t, int kb) __attribute__((always_inline)) {
-    const int u = 2 * t + kb;
-    return (u >= u_cmask && u < u_cend) || u >= u_amask;
-  };
+  // The units are visited in order, so ONE running threshold serves both intervals ([u_cmask, u_cend) and [u_amask, ..)):
+  // a unit needs the mask iff its index has reached mask_lo; the last masked cached unit moves mask_lo on to u_amask
+  // (inside the rare branch).  Hot path per unit: one compare and one branch.
+  int mask_lo = u_cmask < u_cend ? u_cmask : u_amask;
   auto unit_mask = [&](int t, int kb, f32x16(&sc_)[2]) __attribute__((always_inline)) {
     const bool cached = t < ntc;
     const int j0 = (cached ? t * PF_KT : (t - ntc) * PF_KT) + 32 * kb;
@@ -1171,7 +1171,10 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (unit_needs_mask(tn, kbn)) unit_mask(tn, kbn, sn_);
+    if (2 * tn + kbn >= mask_lo) {
+      unit_mask(tn, kbn, sn_);
+      if (mask_lo < u_cend && 2 * tn + kbn + 1 >= u_cend) mask_lo = u_amask;
+    }
     static_for<8, 16>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       constexpr int i = kk >> 1, qb = kk & 1;
@@ -1227,7 +1230,10 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       sX[0] = mfma32<T>(a0, qf[0][s], sX[0]);
       sX[1] = mfma32<T>(a0, qf[1][s], sX[1]);
     }
-    if (unit_needs_mask(0, 0)) unit_mask(0, 0, sX);
+    if (0 >= mask_lo) {
+      unit_mask(0, 0, sX);
+      if (mask_lo < u_cend && 1 >= u_cend) mask_lo = u_amask;
+    }
 #pragma unroll
     for (int part = 0; part < 8; ++part) max_part(sX[part / 4], part % 4, part / 4, mx_raw[part / 4]);
 #if P4_PRESCALE
