@@ -91,6 +91,13 @@ class LLMEngine:
                              per_sequence_compression_params=per_sequence_compression_params,
                              detokenizer_kwargs=detokenizer_kwargs, return_sequences=return_sequences)
 
+    def cache_prefix(self, prompt: PromptLike, batch_compression_params: Optional[BatchCompressionParams] = None, **tokenizer_kwargs) -> int:
+        """Register the first `len // 512 * 512` tokens of `prompt` as a reusable prefix (extension; the reference lists
+        prefix caching as "coming soon", README.md:29-30): later `generate` calls with the same
+        `batch_compression_params` method whose prompts start with those tokens prefill only their suffix.  Returns the
+        number of tokens registered."""
+        return self.master_model_runner.cache_prefix(self.tokenize_prompt(prompt, **tokenizer_kwargs), batch_compression_params)
+
     def generate_from_sequences(self, seqs: List[Sequence], batch_compression_params: BatchCompressionParams):
         self.master_model_runner.generate(seqs, batch_compression_params)
         return seqs

@@ -37,6 +37,7 @@ from ..utils.chunked import ChunkedPrefillState, PrefillChunk, chunk_boundaries
 from ..utils.context import CompressionContext, reset_context, set_context
 from ..utils.sequence import Sequence
 from .memory_manager import KVCacheManager, attention_modules
+from .prefix_cache import PREFIX_ALIGN, PrefixCache, PrefixEntry
 from .scheduler import Scheduler
 
 logger = logging.getLogger(__name__)
@@ -77,6 +78,9 @@ class ModelRunner:
         # single-threaded and replays on the current stream).
         self._capture_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.last_scheduler: Optional[Scheduler] = None
+        self.prefix_cache = PrefixCache()
+        self._batch_params: Optional[BatchCompressionParams] = None
+        self.kv_manager.goes_alone = self._has_prefix_hit
 
     # ------------------------------------------------------------------------------------------------ prefill
     @torch.inference_mode()
@@ -97,15 +101,19 @@ class ModelRunner:
             reset_context()
 
     @torch.inference_mode()
-    def run_prefill_chunked(self, a: PrefillBatchArguments, batch_mapping: torch.Tensor) -> torch.Tensor:
+    def run_prefill_chunked(self, a: PrefillBatchArguments, batch_mapping: torch.Tensor, *, start: int = 0,
+                            state: Optional[ChunkedPrefillState] = None, finish: bool = True) -> torch.Tensor:
         """One sequence whose prompt exceeds `max_batched_tokens`: chunks of a multiple of 512 tokens, each
         attending to [its own cached prefix || itself] and written to the cache uncompressed; scoring state carried in
         a `ChunkedPrefillState`; compression applied in place after the last chunk (layers/attention.py).  Returns the
-        logits of the prompt's last token."""
+        logits of the prompt's last token.  `start` / `state`: the first `start` tokens are in the cache already and
+        `state` holds their scoring stash (prefix reuse); `finish=False`: no chunk is the last one (a prefix being
+        registered: nothing is compressed, the state is the caller's to keep)."""
         assert a.B == 1
         total = int(a.context_lens[0])
-        cuts = chunk_boundaries(total, self.max_batched_tokens)
-        state = ChunkedPrefillState(total, self.num_kv_heads, attention_modules(self.model))
+        cuts = [start + c for c in chunk_boundaries(total - start, self.max_batched_tokens)]
+        if state is None:
+            state = ChunkedPrefillState(total, self.num_kv_heads, attention_modules(self.model))
         logits = None
         for ci in range(len(cuts) - 1):
             s0, s1 = cuts[ci], cuts[ci + 1]
@@ -116,7 +124,7 @@ class ModelRunner:
                 batch_tokens_to_retain=a.batch_tokens_to_retain, max_tokens_to_retain=a.max_tokens_to_retain,
                 context_lens=[n], PHI=a.PHI, protected_first_tokens=a.protected_first,
                 protected_last_tokens=a.protected_last)
-            last = ci == len(cuts) - 2
+            last = finish and ci == len(cuts) - 2
             state.begin_chunk()
             set_context(is_prefill=True, do_compression=a.do_compression, cu_seqlens_q=cu, cu_seqlens_k=cu,
                         max_seqlen_q=n, max_seqlen_k=n, batch_mapping=batch_mapping, max_bh_len=s0,
@@ -131,6 +139,88 @@ class ModelRunner:
                 reset_context()
             self._join_store_stream()  # the next chunk's attention reads this chunk's rows and lengths
         return logits
+
+    # ------------------------------------------------------------------------------------------------ prefix reuse
+    def _scoring_key(self, params: BatchCompressionParams):
+        return params.compression_method, (params.chunk_size if params.do_chunked_compression else -1)
+
+    @torch.inference_mode()
+    def cache_prefix(self, token_ids: List[int], batch_compression_params: Optional[BatchCompressionParams] = None) -> int:
+        """Register the first P = len // 512 * 512 tokens as a reusable prefix (core/prefix_cache.py): prefilled once,
+        uncompressed, into a resident cache row, with the scoring state of `batch_compression_params`' method.  Returns
+        P (0: nothing registered - too short, already known, or no room)."""
+        from ..compression.compression_config import CompressionMethod
+        from ..compression.compression_config import SequenceCompressionParams
+        from ..config.sampling_params import SamplingParams
+
+        params = batch_compression_params if batch_compression_params is not None else BatchCompressionParams()
+        method, chunk = self._scoring_key(params)
+        P = (len(token_ids) // PREFIX_ALIGN) * PREFIX_ALIGN
+        if P == 0 or P + 1 > self.max_model_len:
+            return 0
+        toks = tuple(int(t) for t in token_ids[:P])
+        if self.prefix_cache.lookup(list(toks) + [0], method, chunk, 1) is not None:
+            return P
+        owner = self.prefix_cache.next_owner_id()
+        ok, rows = self.kv_manager.allocate_sequences([owner], [P])
+        if not ok:
+            self.kv_manager.free_sequences([owner])
+            return 0
+        # ratio < 1 only so that the scoring hooks run; nothing is ever evicted from a prefix row (finish=False)
+        seq = Sequence(list(toks), sampling_params=SamplingParams(0.0, 1),
+                       compression_params=SequenceCompressionParams(0.5 if method != CompressionMethod.NONE else 1.0, 0, 0))
+        a = build_prefill_args([seq], params, self.num_kv_heads, self.PHI, self.device)
+        state = ChunkedPrefillState(P, self.num_kv_heads, attention_modules(self.model))
+        self.run_prefill_chunked(a, rows, state=state, finish=False)
+        self._join_store_stream()
+        torch.cuda.current_stream(self.device).synchronize() if self.on_gpu else None
+        self.prefix_cache.add(PrefixEntry(tokens=toks, length=P, row=int(rows[0]), owner_id=owner, method=method,
+                                          chunk_size=chunk, pre=dict(state.pre), mass=dict(state.mass)))
+        return P
+
+    def drop_prefixes(self) -> None:
+        """Release every registered prefix's cache row."""
+        for e in self.prefix_cache.pop_all():
+            self.kv_manager.free_sequences([e.owner_id])
+
+    def _min_suffix(self, params: BatchCompressionParams) -> int:
+        from ..compression.compression_config import CompressionMethod
+
+        return 32 if params.compression_method == CompressionMethod.SNAPKV else 1  # SnapKV's window sits in the suffix
+
+    def _has_prefix_hit(self, seq: Sequence) -> bool:
+        params = self._batch_params
+        if params is None or not self.prefix_cache.entries:
+            return False
+        method, chunk = self._scoring_key(params)
+        return self.prefix_cache.lookup(seq.prompt_token_ids, method, chunk, self._min_suffix(params)) is not None
+
+    @torch.inference_mode()
+    def run_prefill_with_prefix(self, a: PrefillBatchArguments, batch_mapping: torch.Tensor, entry: PrefixEntry) -> torch.Tensor:
+        """The request's row receives a copy of the prefix's K/V pages (every layer, every head), its lengths start at
+        P, and the suffix runs as the remaining chunk(s) of a chunked prefill whose scoring state starts from the
+        prefix's stash."""
+        cache = self.kv_manager.paged_cache
+        P, PS = entry.length, cache.page_size
+        npg = P // PS
+        row = int(batch_mapping[0])
+        L, H = cache.num_layers, cache.H_kv
+        src = cache.page_table[:, entry.row, :, :npg].long()  # [L, H, npg] physical pages
+        dst = cache.page_table[:, row, :, :npg].long()
+        kv = cache.kv_cache.view(2, L, cache.n_pages, PS, cache.head_dim)
+        li = torch.arange(L, device=src.device)[:, None, None].expand_as(src)
+        kv[:, li, dst] = kv[:, li, src]
+        cache.bh_seq_lens[:, row] = P
+        total = int(a.context_lens[0])
+        state = ChunkedPrefillState(total, self.num_kv_heads, attention_modules(self.model))
+        for layer, t in entry.mass.items():
+            state.mass[layer] = torch.empty((total, self.num_kv_heads), dtype=t.dtype, device=t.device)
+            state.mass[layer][:P] = t[:P]
+        for layer, t in entry.pre.items():
+            state.pre[layer] = torch.empty((total, self.num_kv_heads), dtype=t.dtype, device=t.device)
+            state.pre[layer][:P] = t[:P]
+        entry.hits += 1
+        return self.run_prefill_chunked(a, batch_mapping, start=P, state=state)
 
     def _join_store_stream(self) -> None:
         if self.store_stream is not None:
@@ -163,6 +253,7 @@ class ModelRunner:
     @torch.inference_mode()
     def generate(self, all_sequences: List[Sequence], batch_compression_params: Optional[BatchCompressionParams] = None):
         params = batch_compression_params if batch_compression_params is not None else BatchCompressionParams()
+        self._batch_params = params  # the scheduler asks `_has_prefix_hit` through the KV manager
         sched = Scheduler(all_sequences, self.kv_manager, use_tqdm=bool(self.config.show_progress_bar))
         self.last_scheduler = sched
         batch = DecodeBatchArguments()
@@ -180,7 +271,13 @@ class ModelRunner:
                         raise RuntimeError("failed to allocate pages for sequences")
                     temps = torch.tensor([s.sampling_params.temperature for s in seqs], dtype=torch.float32,
                                          device=self.device)
-                    if len(seqs) == 1 and seqs[0].prompt_len > self.max_batched_tokens:
+                    hit = None
+                    if len(seqs) == 1 and self.prefix_cache.entries:
+                        method, chunk = self._scoring_key(params)
+                        hit = self.prefix_cache.lookup(seqs[0].prompt_token_ids, method, chunk, self._min_suffix(params))
+                    if hit is not None:
+                        logits = self.run_prefill_with_prefix(args, rows, hit)
+                    elif len(seqs) == 1 and seqs[0].prompt_len > self.max_batched_tokens:
                         logits = self.run_prefill_chunked(args, rows)
                     else:
                         logits = self.run_prefill(args, rows)

@@ -45,12 +45,17 @@ class Scheduler:
         chosen: List[Sequence] = []
         used = 0
         chunked_ok = bool(getattr(self.manager, "chunked_prefill", False))
+        goes_alone = getattr(self.manager, "goes_alone", None)  # set by the runner: prompt starts with a registered prefix
         for seq_id in self.pending_sequence_ids:
             seq = self.allseq_mapping[seq_id]
             need = cdiv(seq.prompt_len + seq.sampling_params.max_new_tokens, page_size) * heads
-            if chunked_ok and not chosen and seq.prompt_len > budget and rows > 0 and need < pages:
-                # extension: a prompt longer than one prefill launch goes alone and is prefilled in chunks
-                return [seq]
+            alone = seq.prompt_len > budget or (goes_alone is not None and goes_alone(seq))
+            if chunked_ok and alone:
+                # extension: a prompt longer than one prefill launch, or one that starts with a registered
+                # prefix, goes alone and is prefilled in chunks (over its cached prefix)
+                if not chosen and rows > 0 and need < pages:
+                    return [seq]
+                continue
             if seq.prompt_len + used <= budget and rows > 0 and need < pages:
                 chosen.append(seq)
                 used += seq.prompt_len

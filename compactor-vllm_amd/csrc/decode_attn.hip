@@ -922,6 +922,21 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ 
     const int HKV = HQ / G, h = hq / G;
     if (bt != reserved) seq_lens[lens_by_row ? bt * HKV + h : b * HKV + h] += 1;
   }
+  // The first batch of partial rows does not depend on the lse words: both sets of loads are issued together, so the
+  // kernel pays ONE memory round trip before its arithmetic instead of two (it is a chain of dependent latencies: 32
+  // workgroups, nothing to hide them behind).  Rows of splits >= S are clamped to split 0 and weighted 0.
+  auto load_rows = [&](int s0, float (&v)[4][VPT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = s0 + wave + 4 * i;
+      const int sc = s < S ? s : 0;
+      const float* po = part_o + ((size_t)(b * S + sc) * HQ + hq) * D + lane * VPT;
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) v[i][j] = po[j];
+    }
+  };
+  float v[4][VPT];
+  load_rows(0, v);
   float lse[DEC_MAX_SPLITS / 64];
   float M = -INFINITY;
 #pragma unroll
@@ -941,9 +956,10 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ 
   float acc[VPT];
 #pragma unroll
   for (int j = 0; j < VPT; ++j) acc[j] = 0.f;
-  for (int s0 = 0; s0 < S; s0 += 16) {  // 4 independent partial rows per wave in flight
+  for (int s0 = 0; s0 < S; s0 += 16) {  // 4 independent partial rows per wave, the next batch in flight behind them
+    float vn[4][VPT];
+    if (s0 + 16 < S) load_rows(s0 + 16, vn);
     float w[4];
-    float v[4][VPT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int s = s0 + wave + 4 * i;
@@ -952,10 +968,6 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ 
       for (int j = 0; j < DEC_MAX_SPLITS / 64; ++j)
         if ((s >> 6) == j) w[i] = __shfl(lse[j], s & 63, 64);
       if (s >= S) w[i] = 0.f;
-      const int sc = s < S ? s : 0;  // clamp: always a valid address; weight 0 discards it
-      float* po = part_o + ((size_t)(b * S + sc) * HQ + hq) * D + lane * VPT;
-#pragma unroll
-      for (int j = 0; j < VPT; ++j) v[i][j] = po[j];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -967,6 +979,12 @@ __global__ __launch_bounds__(256) void decode_stage2_kernel(float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < VPT; ++j) po[j] = 0.f;
       }
+    }
+    if (s0 + 16 < S) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) v[i][j] = vn[i][j];
     }
   }
 #pragma unroll

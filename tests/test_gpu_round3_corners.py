@@ -141,6 +141,7 @@ def test_select_lookback_timeout_raises_status_not_trap(dev):
         assert torch.equal(kept2[0, h, :n], kept_ok[0, h, :n])
 
 
+@torch.inference_mode()  # like the engine: graphs captured earlier in the process registered inference tensors
 def test_decode_merge_modes_and_status_over_all_workspaces(dev):
     """The default split merge is the two-kernel path; `merge_status` looks at every live decode workspace of the device
     (eager stream AND graph capture stream) and stays 0."""
