@@ -596,6 +596,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef P4_PRESCALE
 #define P4_PRESCALE 0
 #endif
+// LDS fragment reads run P4_RA fragments ahead of the MFMAs that consume them (tunable, A/B builds)
+#ifndef P4_RA
+#define P4_RA 3
+#endif
 #if P4_PRESCALE
 // Exp work of a unit = 80 micro-ops (see `micro` in the kernel): item j (two logits of one query block) is exp2, exp2,
 // then - one item late - row-sum add, add, pack.  First micro-op of MFMA slot k: ops are dealt in order, a slot takes ops
@@ -879,6 +883,28 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     st[set][i] = (i < 4) ? __builtin_amdgcn_raw_buffer_load_b128(rk, ld_app ? voffak[i & 3] : voffc[i & 3], 0, 0)
                          : __builtin_amdgcn_raw_buffer_load_b128(rv, ld_app ? voffav[i & 3] : voffc[i & 3], 0, 0);
   };
+  // the same two for loops in which every tile still to be loaded is an appended one (all of a prefill without a cached
+  // prefix): no layout test, no select - two 64-bit adds, two subtracts, eight loads with loop-invariant offsets
+  auto tile_desc_app = [&]() __attribute__((always_inline)) {
+    rk = __builtin_amdgcn_make_buffer_rsrc((void*)a_kp, 0, max(a_remk, 0), 0x00020000);
+    rv = __builtin_amdgcn_make_buffer_rsrc((void*)a_vp, 0, max(a_remv, 0), 0x00020000);
+    a_kp += a_stepk;
+    a_vp += a_stepv;
+    a_remk -= 2 * a_stepk;
+    a_remv -= 2 * a_stepv;
+  };
+#ifdef P4_DECOUPLE_LOADS  // timing-only A/B build (wrong results): the loop's loads land in registers nothing waits for
+  u32x4 sink[8];
+  auto gload_piece_app = [&](int set, int i) __attribute__((always_inline)) {
+    sink[i] = (i < 4) ? __builtin_amdgcn_raw_buffer_load_b128(rk, voffak[i & 3], 0, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(rv, voffav[i & 3], 0, 0);
+  };
+#else
+  auto gload_piece_app = [&](int set, int i) __attribute__((always_inline)) {
+    st[set][i] = (i < 4) ? __builtin_amdgcn_raw_buffer_load_b128(rk, voffak[i & 3], 0, 0)
+                         : __builtin_amdgcn_raw_buffer_load_b128(rv, voffav[i & 3], 0, 0);
+  };
+#endif
   const uint32_t kst = srow * PF_KSTR + sch * 16, vst = srow * PF_VSTR + sch * 16;
   auto lstore_piece = [&](int set, int buf, int i) __attribute__((always_inline)) {
     char* kb = smem + buf * PF_KTILE + kst;
@@ -926,7 +952,10 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
   float mx_raw[2] = {-INFINITY, -INFINITY}, mx_new[2] = {0.f, 0.f};
   u32x4 pw[2][2];   // P fragments of the current unit [query block][keys 0-15 / 16-31]
-  s16x8 kfr[4], vfr[4];  // fragment rings: reads run three fragments ahead of their MFMAs
+  // fragment rings: LDS reads run P4_RA fragments ahead of their MFMAs (lgkmcnt is a 4-bit counter: K reads + V
+  // preloads + staging writes in flight must stay below 16)
+  constexpr int RA = P4_RA, RING = P4_RA + 1;
+  s16x8 kfr[RING], vfr[RING];
 
 #if P4_PRESCALE
   // The exp work of a unit as a list of 80 micro-ops, dealt to the unit's first 24 MFMA shadows by issue cost
@@ -1126,13 +1155,14 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
 #endif
   // phase A of a unit: S(next) = K[next unit] Q^T beside the first ITEMS_A exp items of the current unit.
-  // Entry: kfr[0..2] hold k-steps 0-2 of the next unit's K block.  Exit: vfr[0..2] hold this unit's first V fragments.
+  // Entry: kfr[0..RA-1] hold the first k-steps of the next unit's K block.  Exit: vfr[0..RA-1] hold this unit's first V
+  // fragments.
   auto phase_a = [&](const lds_char* kbp, const lds_char* vbp, const f32x16(&sc_)[2], f32x16(&sn_)[2], auto extra)
                      __attribute__((always_inline)) {
     static_for<0, 16>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       constexpr int s = kk >> 1, qb = kk & 1;
-      if (qb == 0 && s + 3 < KS) kfr[(s + 3) % 4] = k_read(kbp, s + 3);
+      if (qb == 0 && s + RA < KS) kfr[(s + RA) % RING] = k_read(kbp, s + RA);
       if (s == 0) {
 #if P4_PRESCALE
         sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], negm[qb]);  // the chain starts at minus the running max
@@ -1143,31 +1173,30 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], z);
 #endif
       } else {
-        sn_[qb] = mfma32<T>(kfr[s % 4], qf[qb][s], sn_[qb]);
+        sn_[qb] = mfma32<T>(kfr[s % RING], qf[qb][s], sn_[qb]);
       }
       static_for<p4_mb(kk), p4_mb(kk + 1)>([&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
-      if (kk == 11) vfr[0] = v_read(vbp, 0);
-      if (kk == 13) vfr[1] = v_read(vbp, 1);
-      if (kk == 15) vfr[2] = v_read(vbp, 2);
+      if constexpr ((kk & 1) && kk >= 17 - 2 * RA) vfr[(kk - (17 - 2 * RA)) / 2] = v_read(vbp, (kk - (17 - 2 * RA)) / 2);
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
   // phase B of a unit: O^T += V[unit]^T P^T beside the remaining exp items (first half), then the row max and the
   // running-max bookkeeping of the next unit (second half).  (tn, kbn) = the next unit, whose logits are in sn_.
-  // Exit: kfr[0..2] hold k-steps 0-2 of the K block at kbp_next (the unit after the next).
+  // Exit: kfr[0..RA-1] hold the first k-steps of the K block at kbp_next (the unit after the next).
   auto phase_b = [&](const lds_char* vbp, const lds_char* kbp_next, const f32x16(&sc_)[2], f32x16(&sn_)[2], int tn,
                      int kbn, auto extra) __attribute__((always_inline)) {
     static_for<0, 8>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       constexpr int i = kk >> 1, qb = kk & 1;
-      if (qb == 0) vfr[(i + 3) % 4] = v_read(vbp, i + 3);
-      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][0]));
+      if (qb == 0 && i + RA < 8) vfr[(i + RA) % RING] = v_read(vbp, i + RA);
+      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % RING], __builtin_bit_cast(s16x8, pw[qb][0]));
 #if P4_MFMA_ROWSUM && !P4_PRESCALE
       if constexpr (kk < 2) lsum[qb] = mfma32<T>(ones, __builtin_bit_cast(s16x8, pw[qb][0]), lsum[qb]);
 #endif
       static_for<p4_mb(16 + kk), p4_mb(16 + kk + 1)>(
           [&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
+      if constexpr ((kk & 1) && kk >= 17 - 2 * RA) kfr[(kk - (17 - 2 * RA)) / 2] = k_read(kbp_next, (kk - (17 - 2 * RA)) / 2);
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1178,25 +1207,20 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     static_for<8, 16>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       constexpr int i = kk >> 1, qb = kk & 1;
-      if (qb == 0 && i + 3 < 8) vfr[(i + 3) % 4] = v_read(vbp, i + 3);
-      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % 4], __builtin_bit_cast(s16x8, pw[qb][1]));
+      if (qb == 0 && i + RA < 8) vfr[(i + RA) % RING] = v_read(vbp, i + RA);
+      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % RING], __builtin_bit_cast(s16x8, pw[qb][1]));
 #if P4_MFMA_ROWSUM && !P4_PRESCALE
       if constexpr (kk < 10) lsum[qb] = mfma32<T>(ones, __builtin_bit_cast(s16x8, pw[qb][1]), lsum[qb]);
 #endif
       if constexpr (kk < 14) max_part(sn_[(kk - 8) / 3], (kk - 8) % 3, (kk - 8) / 3, mx_raw[(kk - 8) / 3]);
-      if (kk == 11) {
-        max_part(sn_[0], 3, 0, mx_raw[0]);  // exchange of query block 0, one slot after its part 2
-        kfr[0] = k_read(kbp_next, 0);
-      }
-      if (kk == 13) kfr[1] = k_read(kbp_next, 1);
+      if (kk == 11) max_part(sn_[0], 3, 0, mx_raw[0]);  // exchange of query block 0, one slot after its part 2
       if (kk == 14) {
         max_part(sn_[1], 3, 1, mx_raw[1]);
         chain(0);
       }
-      if (kk == 15) {
-        chain(1);
-        kfr[2] = k_read(kbp_next, 2);
-      }
+      if (kk == 15) chain(1);
+      // the next phase A's first RA K fragments, one per odd slot up to the last one
+      if constexpr ((kk & 1) && kk >= 17 - 2 * RA) kfr[(kk - (17 - 2 * RA)) / 2] = k_read(kbp_next, (kk - (17 - 2 * RA)) / 2);
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1254,9 +1278,8 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     rescale_if_grew(sX);  // O and l are still zero: this only moves the running max
 #endif
     const lds_char* kb1 = k_ptr(0, 1);
-    kfr[0] = k_read(kb1, 0);
-    kfr[1] = k_read(kb1, 1);
-    kfr[2] = k_read(kb1, 2);
+#pragma unroll
+    for (int f = 0; f < RA; ++f) kfr[f] = k_read(kb1, f);
   }
   // tile 1 (set 1) to LDS; its set then receives tile 3
 #pragma unroll
@@ -1268,8 +1291,9 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
   // one tile = two units.  SET (compile-time) = t & 1: the register set that holds tile t+2 on entry and receives
   // tile t+4; cur = t % 3 = the LDS buffer of tile t.
-  auto tile_body = [&](int t, int cur, auto set_c) __attribute__((always_inline)) {
+  auto tile_body = [&](int t, int cur, auto set_c, auto app_c) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
+    constexpr bool APP = decltype(app_c)::value;  // every tile loaded from here on is an appended one
     const int nxt = cur == 2 ? 0 : cur + 1;   // (t + 1) % 3
     const int nxt2 = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
     // unit (t, keys 0-31): logits in sX; the next unit is (t, keys 32-63), then (t + 1, keys 0-31)
@@ -1287,26 +1311,45 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         if (kk & 1) lstore_piece(SET, nxt2, kk >> 1);
       });
       phase_b(vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, [&](int kk) __attribute__((always_inline)) {
-        if (kk == 0) tile_desc(t + 4);
-        if (kk & 1) gload_piece(SET, kk >> 1);
+        if constexpr (APP) {
+          if (kk == 0) tile_desc_app();
+          if (kk & 1) gload_piece_app(SET, kk >> 1);
+        } else {
+          if (kk == 0) tile_desc(t + 4);
+          if (kk & 1) gload_piece(SET, kk >> 1);
+        }
       });
     }
+#ifndef P4_NO_BARRIER  // timing-only A/B build (wrong results): what the one barrier per tile costs
     lds_barrier();
+#endif
   };
   // Pairs of tiles, then an odd last one: with the second body under an `if` inside the loop, hipcc's wait-count
   // pass merges "set 0 loaded last" into the loop header and drains vmcnt to 0 in front of every LDS write of set 0.
   int cur = 0;  // t % 3
   PF_RT(1);
   int t = 0;
-  for (; t + 1 < ntiles; t += 2) {
-    tile_body(t, cur, std::integral_constant<int, 0>{});
+  // pairs whose loads (tiles t + 4, t + 5) may still be cached tiles: the generic descriptor step
+  for (; t + 1 < ntiles && t + 4 < ntc; t += 2) {
+    tile_body(t, cur, std::integral_constant<int, 0>{}, std::false_type{});
     cur = cur == 2 ? 0 : cur + 1;
-    tile_body(t + 1, cur, std::integral_constant<int, 1>{});
+    tile_body(t + 1, cur, std::integral_constant<int, 1>{}, std::false_type{});
     cur = cur == 2 ? 0 : cur + 1;
   }
-  if (t < ntiles) tile_body(t, cur, std::integral_constant<int, 0>{});
+  // t + 4 >= ntc from here on: only appended tiles (or nothing) are left to load
+  for (; t + 1 < ntiles; t += 2) {
+    tile_body(t, cur, std::integral_constant<int, 0>{}, std::true_type{});
+    cur = cur == 2 ? 0 : cur + 1;
+    tile_body(t + 1, cur, std::integral_constant<int, 1>{}, std::true_type{});
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  if (t < ntiles) tile_body(t, cur, std::integral_constant<int, 0>{}, std::true_type{});
   PF_RT(2);
 
+#ifdef P4_DECOUPLE_LOADS
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(sink[i]));
+#endif
   // ---- epilogue: normalise, stage O through LDS (wave-private region), store whole rows ---------------------------
   acc_settle();
   char* ob = smem + wave * (64 * PF_OSTRIDE);
