@@ -157,7 +157,7 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
     n_splits = dk.plan_internal_splits(B * cfg.kv_heads, model.attn[0].page_table.shape[-1] * model.attn[0].page_size,
                                        None)
     fits = B * cfg.kv_heads * n_splits <= dk._cus(dev.index)
-    one_kernel = n_splits == 1 or (fits and os.environ.get("CVLLM_DECODE_MERGE", "").startswith("i"))
+    one_kernel = n_splits == 1 or (fits and not os.environ.get("CVLLM_DECODE_MERGE", "").startswith(("t", "2")))
     traffic, traffic_src = pmc_traffic(workload, int(avg_bytes))
     out = {"bound": "hbm",
            "kernel": "decode_fused_kernel (K/V streaming + in-launch split merge: the whole of reference a2)"

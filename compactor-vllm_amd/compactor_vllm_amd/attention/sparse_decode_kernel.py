@@ -45,16 +45,16 @@ _MERGE_MODES = {"default": 0, "two-kernel": 1, "in-launch": 2}
 
 
 def set_merge_mode(mode: str) -> str:
-    """Process-wide choice of the split merge for grids that fit the chip: "two-kernel" (fp32 partials +
-    decode_stage2_kernel; the default), "in-launch" (one launch, needs every workgroup co-resident: poll `merge_status`),
-    "default" (the environment's CVLLM_DECODE_MERGE, else two-kernel).  Returns the previous setting.  A captured graph
-    keeps the mode it was captured with."""
+    """Process-wide choice of the split merge for grids that fit the chip: "in-launch" (one launch, the default; needs
+    every workgroup co-resident: poll `merge_status`), "two-kernel" (fp32 partials + decode_stage2_kernel), "default" (the
+    environment's CVLLM_DECODE_MERGE, else in-launch).  Returns the previous setting.  A captured graph keeps the mode it
+    was captured with."""
     prev = int(_lib.lib().cvllm_decode_set_merge_mode(_MERGE_MODES[mode]))
     return {v: k for k, v in _MERGE_MODES.items()}[prev]
 
 
 def merge_status(device: torch.device | None = None) -> int:
-    """Health check of the in-launch split merge (only used with CVLLM_DECODE_MERGE=in-launch) over EVERY live decode
+    """Health check of the in-launch split merge over EVERY live decode
     workspace of the device - graphs launch on their capture stream's workspace, eager calls on the current stream's, so
     looking at one stream's buffer would miss the others.  Synchronises the device.  0 = fine; 1 = some call gave up
     waiting for a sibling split (its output rows hold NaN) - the affected workspaces are re-zeroed here so that later

@@ -239,15 +239,20 @@ class ModelRunner:
                                "before it (cvllm_select_status); the retained sets of this prefill are incomplete")
 
     def _check_decode_health(self) -> None:
-        """Once per generate call: the in-launch split merge's error word of every decode workspace (only ever raised
-        with CVLLM_DECODE_MERGE=in-launch; the default two-kernel merge has no wait that can expire)."""
+        """After every decode loop (the loop has just copied its tokens to the host, so the device is idle): the
+        in-launch split merge's error word of every decode workspace.  A bounded wait that expired means the launch's
+        workgroups were not co-resident (CU mask, shared GPU): the process switches to the two-kernel merge for good,
+        drops the graphs that captured the in-launch form, and raises - the tokens of this call are invalid."""
         if not self.on_gpu:
             return
-        from ..attention.sparse_decode_kernel import merge_status
+        from ..attention.sparse_decode_kernel import merge_status, set_merge_mode
 
         if merge_status(self.device) != 0:
-            raise RuntimeError("decode attention: an in-launch split merge timed out (cvllm_decode_merge_status); "
-                               "tokens generated by this call are invalid")
+            set_merge_mode("two-kernel")
+            self.captured_graphs.clear()
+            raise RuntimeError("decode attention: an in-launch split merge timed out (cvllm_decode_merge_status): the "
+                               "launch's workgroups were not co-resident.  Tokens generated by this call are invalid; "
+                               "the process now uses the two-kernel merge")
 
     # ------------------------------------------------------------------------------------------------ generate
     @torch.inference_mode()
@@ -299,6 +304,7 @@ class ModelRunner:
                     batch.desired_batch_occupancy = len(batch) - 1
                 self._join_store_stream()
                 out, batch = self.run_decode_loop(batch, pending_out)
+                self._check_decode_health()
                 pending_out = []
                 finished = sched.get_finished_sequence_ids_from_unfinished(batch.seq_ids.tolist() if len(batch) else [])
                 sched.record_finished_sequence_ids(finished, update_status=True)
@@ -306,7 +312,6 @@ class ModelRunner:
                 sched.update_sequences(out.output_tokens.tolist(), out.output_seq_ids.tolist())
         finally:
             sched.close()
-        self._check_decode_health()
         return all_sequences
 
     # ------------------------------------------------------------------------------------------------ decode loop

@@ -729,7 +729,11 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
       sMl[2 * g_t + 1] = pden;
     }
     if (tid == 0) *sFail = 0;
+#ifdef CVLLM_DEC_WITHHOLD  // tools/dbg test build only: split 1 never sends its numerators (and the waits are 2 ms)
+    if (owner && s != 1) {
+#else
     if (owner) {
+#endif
 #pragma unroll
       for (int o = 0; o < OPT; ++o) {
         const int e = tid * OPT + o;
@@ -785,7 +789,11 @@ __global__ __launch_bounds__(NW * 64) void decode_fused_kernel(
             }
           }
         if (__all(ok)) break;
+#ifdef CVLLM_DEC_WITHHOLD
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000ull) {  // 2 ms
+#else
         if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {  // 0.5 s: a sibling split never arrived
+#endif
           if (lane == 0) {
             *sFail = 1;
             __hip_atomic_fetch_or((gu32*)(uintptr_t)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1068,18 +1076,20 @@ static int device_cus() {
   return cus[dev];
 }
 
-// Which split merge runs when the grid fits the chip.  Default: the two-kernel path (fp32 partials +
-// decode_stage2_kernel) - it needs no co-residency, cannot time out and measures the same (profiles/r02_decode_kernel_
-// durations.txt: 22.57 us in-launch against 18.19 + 4.74 us; r03 A/B inside the engine's graph in profiles/).
-// CVLLM_DECODE_MERGE=in-launch opts into the one-launch form (callers must then poll cvllm_decode_merge_status);
-// CVLLM_DECODE_MERGE=two-kernel states the default explicitly.
+// Which split merge runs when the grid fits the chip (one ring workgroup per CU, all resident).  Default: inside the
+// launch - chosen by the measurement the round-2 review asked for: rocprofv3 --kernel-trace of the C3 launch INSIDE the
+// engine's HIP graph reads 23.68 us for the one kernel against 20.15 + 4.75 us for stage 1 + decode_stage2_kernel on the
+// same box (profiles/r03_decode_merge_ab.txt; tokens/s +0.26 %).  The in-launch form assumes co-residency, which a plain
+// launch cannot guarantee: every wait is bounded, a timeout raises the sticky error word, and the engine polls it after
+// every decode loop and falls back to the two-kernel path for the rest of the process (core/model_runner.py).
+// CVLLM_DECODE_MERGE=two-kernel (or cvllm_decode_set_merge_mode(1)) forces the two-kernel path.
 static int g_merge_override = 0;  // cvllm_decode_set_merge_mode: 0 = environment / default, 1 = two-kernel, 2 = in-launch
 static bool merge_in_launch_allowed() {
   if (g_merge_override) return g_merge_override == 2;
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CVLLM_DECODE_MERGE");
-    v = (e && (e[0] == 'i' || e[0] == '1')) ? 1 : 0;
+    v = (e && (e[0] == 't' || e[0] == '2')) ? 0 : 1;
   }
   return v == 1;
 }
@@ -1264,7 +1274,7 @@ extern "C" int cvllm_decode_append_attn(const void* q, const void* key, const vo
 }
 
 // Process-wide choice of the split merge for grids that fit the chip (host state, not a launch): 0 = what the
-// environment says (CVLLM_DECODE_MERGE, default two-kernel), 1 = two-kernel, 2 = in-launch.  Returns the previous value.
+// environment says (CVLLM_DECODE_MERGE, default in-launch), 1 = two-kernel, 2 = in-launch.  Returns the previous value.
 extern "C" int cvllm_decode_set_merge_mode(int mode) {
   const int prev = g_merge_override;
   if (mode >= 0 && mode <= 2) g_merge_override = mode;

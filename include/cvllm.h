@@ -48,12 +48,13 @@ const char* cvllm_error_string(int status);
  * current token); page_table[*,HKV,n_logical_pages_max]; batch_mapping[B]; out[B,HQ,D].
  * n_splits is the number of key splits the kernel uses internally (>=1).  With n_splits > 1 `workspace`
  * (cvllm_decode_workspace_bytes) is required and MUST BE ZERO when first handed to the library; every completed
- * call leaves it zero again.  The splits are merged by a second kernel (fp32 partials; the default), or - opt-in,
- * CVLLM_DECODE_MERGE=in-launch, and only when B*HKV*n_splits fits the device's CUs - inside the one launch: workgroups
- * exchange partials through self-validating mailbox words in the workspace.  THE IN-LAUNCH FORM ASSUMES EVERY WORKGROUP
- * OF THE GRID IS CO-RESIDENT; a plain launch does not guarantee that (CU masks, a shared GPU, a long kernel on another
- * stream), so every wait is bounded (0.5 s), a timed-out slice is written as NaN and the sticky error word is raised:
- * callers of that mode must poll cvllm_decode_merge_status.  One workspace serves one
+ * call leaves it zero again.  When B*HKV*n_splits fits the device's CUs the splits are merged inside the one launch
+ * (workgroups exchange partials through self-validating mailbox words in the workspace); otherwise, or with
+ * CVLLM_DECODE_MERGE=two-kernel / cvllm_decode_set_merge_mode(1), fp32 partials are merged by a second kernel.  THE
+ * IN-LAUNCH FORM ASSUMES EVERY WORKGROUP OF THE GRID IS CO-RESIDENT; a plain launch does not guarantee that (CU masks, a
+ * shared GPU, a long kernel on another stream), so every wait is bounded (0.5 s), a timed-out slice is written as NaN
+ * and the sticky error word is raised: callers poll cvllm_decode_merge_status (the engine does after every decode
+ * loop and then falls back to the two-kernel path).  One workspace serves one
  * stream at a time.  Rows with L==0 produce zeros (reference: uninitialised, quirk Q6).
  * Any n_logical_pages_max is accepted (page ids are windowed through registers 512 at a time).              */
 size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits);
@@ -61,7 +62,7 @@ size_t cvllm_decode_workspace_bytes(int B, int HQ, int D, int n_splits);
  * (that call's outputs are NaN; re-zero the workspace), negative = error                                     */
 int cvllm_decode_merge_status(const void* workspace, cvllm_stream_t stream);
 /* process-wide choice of the split merge for grids that fit the chip (host state only): 0 = environment
- * (CVLLM_DECODE_MERGE=in-launch|two-kernel; default two-kernel), 1 = two-kernel, 2 = in-launch; returns the previous
+ * (CVLLM_DECODE_MERGE=in-launch|two-kernel; default in-launch), 1 = two-kernel, 2 = in-launch; returns the previous
  * value.  Not to be flipped between the capture and the replay of a graph that must keep its mode (the mode is baked
  * into the captured launch).                                                                                   */
 int cvllm_decode_set_merge_mode(int mode);

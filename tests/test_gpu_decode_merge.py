@@ -73,6 +73,7 @@ def test_decode_merge_paths_agree_with_oracle(dev, merge_mode, dtype, B, HQ, HKV
     assert _ws_is_zero(dev)
 
 
+@torch.inference_mode()  # graph capture after the engine's (inference-mode) graphs in the same process
 def test_decode_in_launch_merge_is_deterministic_under_replay(dev, merge_mode):
     """Back-to-back launches on one workspace (what a decode step's 32 layers and a HIP-graph replay do): every launch
     returns the same bits, eagerly and from a captured graph."""

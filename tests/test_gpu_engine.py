@@ -198,3 +198,58 @@ def test_engine_prefill_cache_and_first_decode_step_equal_oracle(dev, method_nam
                 V = torch.cat([p["v"][src, h], d["v"][i, h][None]]).float()
                 pr = torch.softmax(d["q"][i, h * G : (h + 1) * G].float() @ K.T / math.sqrt(D), -1)
                 assert torch.allclose(d["out"][i, h * G : (h + 1) * G].float(), pr @ V, atol=tol(dtype)), (li, b, h)
+
+
+_FALLBACK_CHILD = r'''
+import os, sys, torch
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "compactor-vllm_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+from tiny_model import TinyConfig, TinyModel
+from compactor_vllm_amd import LLM, LLMConfig, SamplingParams, BatchCompressionParams, CompressionMethod, SequenceCompressionParams
+from compactor_vllm_amd.attention import sparse_decode_kernel as dk
+dev = torch.device("cuda:0")
+cfg = TinyConfig()
+def llm(eager):
+    conf = LLMConfig(model="tiny", max_num_seqs=2, max_model_len=4096, hf_config=cfg, eos=-1, kvcache_page_size=128,
+                     enforce_eager=eager, show_progress_bar=False)
+    return LLM(conf, TinyModel(cfg, dev), device=dev, num_pages=80, max_batched_tokens=4096)
+g = torch.Generator().manual_seed(3)
+prompt = torch.randint(0, 512, (3000,), generator=g).tolist()   # 2 kv heads x splits: the grid fits the chip -> in-launch merge
+sp = SamplingParams(temperature=0.0, max_new_tokens=4)
+bcp = BatchCompressionParams(compression_method=CompressionMethod.NONE)
+eng = llm(False)
+try:
+    eng.generate([prompt], sp, bcp)
+    print("NO_ERROR")
+except RuntimeError as e:
+    print("RAISED" if "in-launch split merge timed out" in str(e) else "OTHER " + str(e)[:200])
+assert dk.set_merge_mode("default") == "two-kernel"      # the runner switched the process over ...
+dk.set_merge_mode("two-kernel")
+assert len(eng.master_model_runner.captured_graphs) == 0  # ... and dropped the graphs that captured the in-launch form
+eng.master_model_runner.kv_manager.free_sequences(list(eng.master_model_runner.kv_manager.seq_id_to_batch))
+out2 = eng.generate([prompt], sp, bcp)                     # the same engine keeps working on the two-kernel merge
+ref = llm(True).generate([prompt], sp, bcp)
+print("FALLBACK_OK" if out2 == ref and dk.merge_status(dev) == 0 else "FALLBACK_MISMATCH")
+'''
+
+
+def test_engine_reports_in_launch_merge_timeout_and_falls_back(dev):
+    """The in-launch split merge assumes co-resident workgroups; when a sibling split never delivers, the merging
+    workgroups give up (bounded wait), the engine's per-decode-loop health check raises, switches the process to the
+    two-kernel merge and drops the captured graphs - and the next call works.  Driven with the debug build
+    tools/dbg/libcvllm_dec_withhold.so (split 1 withholds its numerators) in a child process (CVLLM_LIB_PATH)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "dbg", "libcvllm_dec_withhold.so")
+    if not os.path.exists(lib):
+        pytest.fail("tools/dbg/libcvllm_dec_withhold.so missing: run __graft_entry__.build()")
+    env = dict(os.environ, CVLLM_LIB_PATH=lib)
+    env.pop("CVLLM_DECODE_MERGE", None)
+    r = subprocess.run([sys.executable, "-c", _FALLBACK_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert "RAISED" in lines and "FALLBACK_OK" in lines, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,20 +1,43 @@
 #!/bin/bash
-# Round evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r02
+# Round evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh r03
 # Writes summaries AND the logs of every step into gpurun_out/<round>/ (copy the ones to keep into profiles/; nothing is
 # deleted here but the raw trace directories, whose content the summaries are made from).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 mkdir -p "$O"
 B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq"
-# 1. kernel trace + the tool's own stats of the bench command (C3 through the engine)
+# 1. kernel trace + the tool's own stats of the bench command (C3 through the engine); the decode kernels' mean durations
+#    of THIS trace become profiles/<R>_bench_decode_rocprof.json, which bench.py prints beside its event-timed figure
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- $B > "$O/bench_under_rocprof.log" 2>&1
 python3 tools/prof_summary.py "$O/kt" > "$O/${R}_bench_c3_kernel_summary.txt"
 cp "$(find "$O/kt" -name '*kernel_stats.csv' | head -1)" "$O/${R}_bench_c3_kernel_stats.csv"
 grep "^{\"metric\"" "$O/bench_under_rocprof.log" | tail -1 > "$O/${R}_bench_c3_under_rocprof.json"
+python3 - "$O" "$R" "$B" <<'PY'
+import csv, glob, json, os, statistics, sys
+O, R, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+rows = {}
+for f in glob.glob(os.path.join(O, "kt", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f, newline="")):
+        n = r["Kernel_Name"]
+        if "decode_fused_kernel" in n or "decode_stage2_kernel" in n:
+            key = "decode_fused_kernel" if "fused" in n else "decode_stage2_kernel"
+            rows.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+line = json.load(open(os.path.join(O, f"{R}_bench_c3_under_rocprof.json")))
+# the engine's decode launches (256 rows per workgroup launch = the 256-workgroup C3 grid); the roofline leg's launches of the
+# same shape are part of the same population
+kern = {k: {"n": len(v), "mean_us": round(statistics.mean(v) / 1e3, 2), "median_us": round(statistics.median(v) / 1e3, 2)}
+        for k, v in rows.items()}
+out = {"workload": "C3", "command": f"rocprofv3 --kernel-trace --stats -- {cmd}",
+       "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"], "kernels": kern,
+       "mean_us_per_layer": round(sum(k["mean_us"] for k in kern.values()), 2),
+       "note": "sum of the mean kernel durations of one layer's decode attention (all of its launches), dispatch gaps excluded"}
+json.dump(out, open(os.path.join(O, f"{R}_bench_decode_rocprof.json"), "w"), indent=1)
+print(json.dumps(out))
+PY
 rm -rf "$O/kt"
-echo "[1/7] kernel trace done"
+echo "[1/8] kernel trace done"
 # 2. HBM traffic of the decode-attention kernel INSIDE bench.py (separate --pmc passes), collection limited to the
 #    roofline kernel with --kernel-include-regex.  (An UNFILTERED --pmc pass over every dispatch of bench.py aborted
 #    twice in round 2 with SIGSEGV - profiles/r02_pmc_unfiltered_crash.log; cause not established, see DESIGN.md
@@ -26,42 +49,70 @@ echo "pmc WRITE_SIZE rc=$?" >> "$O/pmc_write.log"
 ALG=$(python3 -c "import json,sys;print(json.load(open('$O/${R}_bench_c3_under_rocprof.json'))['roofline']['algorithmic_bytes_per_launch'])")
 python3 tools/pmc_summary.py "$O/pf" "$O/pw" decode_fused --command "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-include-regex decode_fused --kernel-trace -- $B" --workload C3 --alg-bytes "$ALG" > "$O/${R}_bench_pmc.json"
 rm -rf "$O/pf" "$O/pw"
-echo "[2/7] decode PMC done"
+echo "[2/8] decode PMC done"
 # 3. SQ counters of the prefill kernel (two passes of 8 counters)
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/s1" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq1.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$O/s2" -- python3 tools/microbench.py prefill --L 32768 > "$O/sq2.log" 2>&1
-{ echo "prefill attention (prefill_attn_w4_kernel<BF16,4>), 1 x 32768 tokens, per launch (SQ counters are in 4-cycle units summed over waves / SIMDs)"; python3 tools/pmc_sq.py "$O/s1" prefill_attn; python3 tools/pmc_sq.py "$O/s2" prefill_attn; } > "$O/${R}_prefill_sq_counters.txt"
+{ echo "prefill attention (prefill_attn_w4_kernel<BF16,4>), 1 x 32768 tokens, per launch (SQ counters are in 4-cycle units summed over waves / SIMDs; SQ_INSTS_VALU counts the MFMAs too)"; python3 tools/pmc_sq.py "$O/s1" prefill_attn; python3 tools/pmc_sq.py "$O/s2" prefill_attn; } > "$O/${R}_prefill_sq_counters.txt"
 rm -rf "$O/s1" "$O/s2"
-echo "[3/7] prefill SQ counters done"
-# 4. per-workgroup phase stamps of the decode kernel on one clock (debug build; back-to-back launches)
-timeout -k 10 200 python3 tools/decode_rt.py > "$O/${R}_decode_phase_stamps.txt" 2>&1
-echo "[4/7] decode stamps done"
-# 5. stand-alone kernel timings; decode with the in-launch merge and with the two-kernel merge on the same box
+echo "[3/8] prefill SQ counters done"
+# 4. decode kernel durations by rocprofv3 at the shapes the bench only event-times (C3 launch, 4 x 32K, one GPU's C5 share)
+for cfg in "1 16640 32" "4 16640 8" "8 65536 4"; do
+  set -- $cfg
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/kt_$1_$2" -- python3 tools/microbench.py decode --B $1 --L $2 --splits $3 > "$O/kt_$1_$2.log" 2>&1
+  { echo "# rocprofv3 --kernel-trace -- python3 tools/microbench.py decode --B $1 --L $2 --splits $3   (in-launch merge, the default)"; grep "^decode" "$O/kt_$1_$2.log"; python3 tools/prof_summary.py "$O/kt_$1_$2" decode; } >> "$O/${R}_decode_kernel_durations.txt"
+  rm -rf "$O/kt_$1_$2"
+done
+CVLLM_DECODE_MERGE=two-kernel timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm2" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/ktm2.log" 2>&1
+{ echo "# CVLLM_DECODE_MERGE=two-kernel rocprofv3 --kernel-trace -- python3 tools/microbench.py decode --B 1 --L 16640 --splits 32"; grep "^decode" "$O/ktm2.log"; python3 tools/prof_summary.py "$O/ktm2" decode; } >> "$O/${R}_decode_kernel_durations.txt"
+rm -rf "$O/ktm2"
+echo "[4/8] decode kernel durations done"
+# 5. stand-alone kernel timings and the rocprof durations of the store-stream kernels
 { python3 tools/microbench.py prefill --L 16384; python3 tools/microbench.py prefill --L 32768;
-  echo "# same, CVLLM_PREFILL=8wave (the 8-wave kernel of round 1):"; CVLLM_PREFILL=8wave python3 tools/microbench.py prefill --L 32768;
   echo "# decode attention, C3 per-layer shape, in-launch split merge (default):"; python3 tools/microbench.py decode --L 16640 --splits 32;
   echo "# same, CVLLM_DECODE_MERGE=two-kernel (stage 1 + decode_stage2_kernel):"; CVLLM_DECODE_MERGE=two-kernel python3 tools/microbench.py decode --L 16640 --splits 32;
-  python3 tools/microbench.py decode --L 65536 --B 8 --splits 4; python3 tools/microbench.py scoring --L 32768; } > "$O/${R}_microbench.txt" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/ktm.log" 2>&1
-CVLLM_DECODE_MERGE=two-kernel timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ktm2" -- python3 tools/microbench.py decode --L 16640 --splits 32 > "$O/ktm2.log" 2>&1
-{ echo "# rocprofv3 --kernel-trace of tools/microbench.py decode --L 16640 --splits 32 (9 caches back to back in a HIP graph)"; echo "# in-launch merge:"; python3 tools/prof_summary.py "$O/ktm" decode; echo "# CVLLM_DECODE_MERGE=two-kernel:"; python3 tools/prof_summary.py "$O/ktm2" decode; } > "$O/${R}_decode_kernel_durations.txt"
-rm -rf "$O/ktm" "$O/ktm2"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/kts" -- python3 tools/microbench.py scoring --L 32768 > "$O/kts.log" 2>&1
-{ echo "# rocprofv3 --kernel-trace of tools/microbench.py scoring --L 32768 (every store-stream kernel at the C3 layer shape, alone on the GPU)"; python3 tools/prof_summary.py "$O/kts"; } > "$O/${R}_scoring_kernel_durations.txt"
+  python3 tools/microbench.py decode --L 16640 --B 4 --splits 8; python3 tools/microbench.py decode --L 65536 --B 8 --splits 4;
+  python3 tools/microbench.py scoring --L 32768 --with-producer; } > "$O/${R}_microbench.txt" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/kts" -- python3 tools/microbench.py scoring --L 32768 --with-producer > "$O/kts.log" 2>&1
+{ echo "# rocprofv3 --kernel-trace of tools/microbench.py scoring --L 32768 --with-producer (every store-stream kernel at the C3 layer shape, alone on the GPU)"; python3 tools/prof_summary.py "$O/kts"; } > "$O/${R}_scoring_kernel_durations.txt"
 rm -rf "$O/kts"
-echo "[5/7] microbench done"
-# 6. the bench lines: default run (C3, with cpu_baseline), C2, C4
+echo "[5/8] microbench done"
+# 6. HBM traffic of every bandwidth-bound store-stream kernel (<= 1.15 x algorithmic)
+RX='store_all|compact_store|leverage|snapkv|chunk_mass|qkv_producer|zscore|sj_|sh_|select_'
+MB="python3 tools/microbench.py scoring --L 32768 --iters 6 --warmup 4 --with-producer"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RX" --kernel-trace --output-format csv -d "$O/spf" -- $MB > "$O/scoring_pmc_fetch.log" 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$RX" --kernel-trace --output-format csv -d "$O/spw" -- $MB > "$O/scoring_pmc_write.log" 2>&1
+python3 tools/pmc_summary.py "$O/spf" "$O/spw" "" > "$O/scoring_pmc_raw.json"
+python3 tools/scoring_pmc_summary.py "$O/scoring_pmc_raw.json" > "$O/${R}_scoring_pmc.json"
+rm -rf "$O/spf" "$O/spw"
+echo "[6/8] scoring PMC done"
+# 7. A/B inside the engine: split merge of decode attention (in-launch default vs two-kernel) and the store-stream overlap
+#    against the same chain on the main stream (--serial-store): tokens/s + the kernels' rocprof durations
+BA="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-multi-seq --no-roofline"
+for mode in in-launch two-kernel; do
+  CVLLM_DECODE_MERGE=$mode $BA > "$O/ab_merge_$mode.log" 2>&1
+  CVLLM_DECODE_MERGE=$mode timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d "$O/ktab_$mode" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq --no-roofline > "$O/ktab_$mode.log" 2>&1
+  { echo "# CVLLM_DECODE_MERGE=$mode: $BA"; grep '^{"metric"' "$O/ab_merge_$mode.log" | python3 -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('  tokens/s', d['value'], ' ms/step', d['ms_per_step'])";
+    echo "# CVLLM_DECODE_MERGE=$mode rocprofv3 --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-roofline (C3 through LLM.generate, HIP-graph decode)"; python3 tools/prof_summary.py "$O/ktab_$mode" decode_; } >> "$O/${R}_decode_merge_ab.txt"
+  rm -rf "$O/ktab_$mode"
+done
+$BA --serial-store > "$O/ab_serial_store.log" 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d "$O/ktab_serial" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq --no-roofline --serial-store > "$O/ktab_serial.log" 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d "$O/ktab_overlap" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq --no-roofline > "$O/ktab_overlap.log" 2>&1
+{ for v in serial_store merge_in-launch; do echo "# $( [ $v = serial_store ] && echo '--serial-store (chain on the main stream)' || echo 'store-stream overlap (default)' ): $BA"; grep '^{"metric"' "$O/ab_$v.log" | python3 -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('  tokens/s', d['value'], ' ms/step', d['ms_per_step'])"; done
+  for v in serial overlap; do echo "# rocprofv3 --kernel-trace, $v: prefill attention and the chain's kernels"; python3 tools/prof_summary.py "$O/ktab_$v" | grep -E "kernel  |prefill_attn|chunk_mass|leverage|sj_|sh_|compact_store|zscore"; done; } > "$O/${R}_overlap_ab.txt"
+rm -rf "$O/ktab_serial" "$O/ktab_overlap"
+echo "[7/8] A/B done"
+# 8. the bench lines: default run (C3, with cpu_baseline), C2, C4; optional (COLLECT_C5=1, ~3 min): one GPU's share of C5
 python3 bench.py > "$O/bench_c3.log" 2>&1
 grep "^{\"metric\"" "$O/bench_c3.log" | tail -1 > "$O/${R}_bench_c3.json"
 python3 bench.py --workload C2 --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench_c2.log" 2>&1
 grep "^{\"metric\"" "$O/bench_c2.log" | tail -1 > "$O/${R}_bench_c2.json"
 python3 bench.py --workload C4 --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench_c4.log" 2>&1
 grep "^{\"metric\"" "$O/bench_c4.log" | tail -1 > "$O/${R}_bench_c4.json"
-echo "[6/7] bench lines done"
-# 7. optional (COLLECT_C5=1, ~3 min): one GPU's share of BASELINE.json configs[4] - 8 sequences of 128K context
 if [ "${COLLECT_C5:-0}" = "1" ]; then
   python3 bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline > "$O/bench_c5.log" 2>&1
   grep "^{\"metric\"" "$O/bench_c5.log" | tail -1 > "$O/${R}_bench_c5_per_gpu.json"
-  echo "[7/7] C5 share done"
 fi
+echo "[8/8] bench lines done"
 ls -la "$O"
