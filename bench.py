@@ -252,6 +252,94 @@ def roofline_prefill_attn(model, ctx, rounds=3):
 
 
 @torch.inference_mode()
+def roofline_scoring(model, ctx):
+    """Third roofline object: the bandwidth-bound store-stream kernels (cache write, compaction, Compactor / SnapKV
+    scoring, the fused producer) at the workload's layer shape, each timed live through its boundary call with HIP events
+    on the launch stream (~30 ms of warm calls first).  `achieved` = ALGORITHMIC bytes (SURVEY 8d formulas) / live time of
+    the call - an upper bound of the kernel's own time where the call launches small helpers too (z-score, casts); the
+    kernel-only rocprofv3 duration and the PMC traffic of the same shape are read from the newest committed
+    profiles/*_scoring_kernel_durations.json / *_scoring_pmc.json (taken at 32768 tokens; omitted for other lengths)."""
+    from compactor_vllm_amd.compression.common import extract_and_store_top_kv
+    from compactor_vllm_amd.compression.compactor import approximate_leverage_scores, non_causal_attn_scores
+    from compactor_vllm_amd.compression.snapkv import query_aware_key_scores
+    from compactor_vllm_amd.kv_cache.store_kv_cache import prefill_store_all_kv
+    from compactor_vllm_amd.layers.rotary_embedding import fused_qkv_rope
+
+    cfg, dev = model.cfg, model.dev
+    HQ, HKV, D, e, L, PS = cfg.heads, cfg.kv_heads, cfg.head_dim, 2, ctx, model.attn[0].page_size
+    a = model.attn[0]
+    qkv = (torch.randn(L, (HQ + 2 * HKV) * D, device=dev) * 0.3).to(torch.bfloat16)
+    q = qkv[:, : HQ * D].view(L, HQ, D)
+    k = qkv[:, HQ * D : (HQ + HKV) * D].view(L, HKV, D)
+    v = qkv[:, (HQ + HKV) * D :].view(L, HKV, D)
+    PHI = (torch.randn(D, 48, device=dev) / 48 ** 0.5).to(torch.bfloat16)
+    cu = torch.tensor([0, L], dtype=torch.int32, device=dev)
+    bm = torch.ones(1, dtype=torch.int32, device=dev)
+    zero = torch.zeros(1, HKV, dtype=torch.int32, device=dev)
+    sc = torch.randn(L, HKV, device=dev)
+    kept = int(round(0.5 * (L - 80) * HKV))
+    retain = torch.tensor([kept], dtype=torch.int32, device=dev)
+    pos = torch.arange(L, device=dev)
+    cs = getattr(model, "rope_cs", None)
+
+    def t_us(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        first = max(e0.elapsed_time(e1) * 1e-3, 2e-5)
+        for _ in range(min(400, int(0.03 / first) + 1)):
+            fn()
+        n = max(5, min(100, int(0.01 / first) + 1))
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    calls = {
+        "store_all_kernel": (4 * L * HKV * D * e, lambda: prefill_store_all_kv(
+            new_keys=k, new_values=v, cu_seqlens_k=cu, max_seqlen_k=L, k_cache=a.k_cache, v_cache=a.v_cache,
+            page_table=a.page_table, bh_lens=zero.clone(), batch_mapping=bm, PAGE_SIZE=PS)),
+        "select + compact_store_kernel": (4 * L * HKV + 4 * (kept + 64 * HKV) * D * e, lambda: extract_and_store_top_kv(
+            sc, cu, L, L * HKV, HKV, k, v, retain, a.page_table, bm, zero.clone(), a.k_cache, a.v_cache, PS)),
+        "leverage_fused2_kernel": (L * HKV * D * e + 4 * L * HKV, lambda: approximate_leverage_scores(
+            k, [L], PHI, normalize=False, chunk_size=512)),
+        "chunk_mass_kernel": (L * (HQ + HKV) * D * e + 4 * L * HKV, lambda: non_causal_attn_scores(
+            q, k, v, cu, L, chunk_size=128, sm_scale=1.0, normalize=False)),
+        "snapkv_kernel (two passes)": (L * HKV * D * e + 32 * HQ * D * e + 4 * L * HKV, lambda: query_aware_key_scores(
+            q, k, cu, cu, w=32, max_seqlen_k=L)),
+    }
+    if cs is not None:
+        calls["qkv_producer_kernel"] = (2 * L * (HQ + HKV) * D * e + 4 * L * D,
+                                        lambda: fused_qkv_rope(qkv, pos, cs, HQ, HKV, D))
+    dur, pmc = {}, {}
+    try:
+        names = sorted(os.listdir(os.path.join(ROOT, "profiles")))
+        dn = [p for p in names if p.endswith("_scoring_kernel_durations.json")]
+        pn = [p for p in names if p.endswith("_scoring_pmc.json")]
+        if L == 32768 and dn:
+            dur = json.load(open(os.path.join(ROOT, "profiles", dn[-1])))
+        if L == 32768 and pn:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pn[-1])))["kernels"]
+    except Exception:  # noqa: BLE001
+        pass
+    out = {}
+    for name, (alg, fn) in calls.items():
+        us = t_us(fn)
+        key = name.split(" ")[-1] if name.startswith("select") else name.split(" ")[0]
+        rp = sum(v["mean_us"] for kname, v in dur.items() if kname.startswith(key)) or None
+        tr = pmc.get(key, {}).get("hbm_bytes_per_launch")
+        out[name] = {"algorithmic_bytes": int(alg), "call_us": round(us, 1), "achieved": round(alg / us / 1e3, 1),
+                     "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "rocprof_kernel_us": rp,
+                     "frac_rocprof": None if not rp else round(alg / rp / 1e3 / HBM_PEAK_GBS, 4), "traffic": tr}
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "shape": f"1 x {L} tokens, HQ {HQ} / HKV {HKV} / D {D}, bf16",
+            "kernels": out,
+            "note": "achieved = algorithmic bytes / live time of the boundary call (HIP events on the launch stream, "
+                    "helpers included); rocprof_kernel_us / traffic from the committed profiles of the same shape "
+                    "(separate rocprofv3 --kernel-trace and --pmc passes over tools/microbench.py scoring)"}
+
+
+@torch.inference_mode()
 def copy_bandwidth_gbs(dev, nbytes=1 << 30, rounds=5):
     """Practical HBM roof next to the 8 TB/s spec: a device-to-device copy of 1 GiB (read + write =
     2 GiB moved) timed with events on the current stream."""
@@ -512,6 +600,10 @@ def main():
             result["roofline_prefill"] = roofline_prefill_attn(model, ctx)
         except Exception as exc:  # noqa: BLE001 - secondary object, see above
             result["roofline_prefill"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        try:
+            result["roofline_scoring"] = roofline_scoring(model, ctx)
+        except Exception as exc:  # noqa: BLE001 - secondary object
+            result["roofline_scoring"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         llm.master_model_runner.kv_manager.free_sequences(state["ids"])
         if multi_leg:
             # an extra leg must never cost the main line: anything going wrong here is reported, not raised

@@ -75,6 +75,7 @@ echo "[4/8] decode kernel durations done"
   python3 tools/microbench.py scoring --L 32768 --with-producer; } > "$O/${R}_microbench.txt" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/kts" -- python3 tools/microbench.py scoring --L 32768 --with-producer > "$O/kts.log" 2>&1
 { echo "# rocprofv3 --kernel-trace of tools/microbench.py scoring --L 32768 --with-producer (every store-stream kernel at the C3 layer shape, alone on the GPU)"; python3 tools/prof_summary.py "$O/kts"; } > "$O/${R}_scoring_kernel_durations.txt"
+python3 tools/prof_summary.py "$O/kts" cvllm --json > "$O/${R}_scoring_kernel_durations.json"
 rm -rf "$O/kts"
 echo "[5/8] microbench done"
 # 6. HBM traffic of every bandwidth-bound store-stream kernel (<= 1.15 x algorithmic)
