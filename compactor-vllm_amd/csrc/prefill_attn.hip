@@ -209,6 +209,55 @@ __device__ __forceinline__ void acc_zero_all() {
 // every asm MFMA issued so far has written its accumulator (8-pass XDL write -> v_accvgpr_read: 18 wait states cover it)
 __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
+// The 4-wave kernel's softmax state that its RARE path rewrites - reference points, row sums, packed P words - lives in
+// arch VGPRs v230..v255 owned by inline asm in the same way (the kernel is compiled with amdgpu_num_vgpr(230): hipcc
+// allocates v0..v229).  Why: a value the compiler can see being rewritten inside a conditional block gets a second home
+// register there, and the copies that reconcile the two homes land on the COMMON path (18-26 v_mov per check, measured:
+// as many instructions as the check scheme saves).  Registers nothing visible ever writes need no reconciling.
+//   v222+qb  minus the reference point of query block qb      v224+qb / v226+qb  running sums l (even / odd logits)
+//   v228+qb / v230+qb  the sums of the unit in flight
+//   v232 + 8 par + 4 qb + word  packed P words of keys 0-15 (two sets, by the parity of the unit: the next unit's stream
+//                               writes its set while the PV MFMAs still read this unit's)
+//   v248 + 4 qb + word          packed P words of keys 16-31
+// Hazards are the placement's business, as with the accumulators: a word is packed at least one MFMA shadow before the
+// MFMA that reads it, a v_exp result is read by an asm add two instructions later, the logits an asm fma reads were
+// written by MFMAs at least two shadows earlier.
+constexpr int P4_VNM = 222, P4_VL = 224, P4_VL2 = 226, P4_VLU = 228, P4_VLU2 = 230, P4_VPW0 = 232, P4_VPW1 = 248;
+constexpr int P4_NUM_VGPR = 222;
+// register of the packed word of item j (= 8 s2 + 4 qb + jp) of a unit of parity par
+constexpr int p4_word_reg(int par, int j) {
+  return (j >> 3) ? P4_VPW1 + 4 * ((j >> 2) & 1) + (j & 3) : P4_VPW0 + 8 * par + 4 * ((j >> 2) & 1) + (j & 3);
+}
+template <typename T, int X, int W>
+__device__ __forceinline__ void pv_mfma_w(s16x8 a) {
+  static_assert(X >= P4_ACC0 && X + 15 < 256 && (X % 16) == 0 && W >= P4_VPW0 && W + 3 < 256 && (W % 4) == 0, "registers");
+  if constexpr (std::is_same<T, BF16>::value)
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, v[%c3:%c4], a[%c1:%c2]" ::"v"(a), "i"(X), "i"(X + 15), "i"(W),
+                 "i"(W + 3));
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%c1:%c2], %0, v[%c3:%c4], a[%c1:%c2]" ::"v"(a), "i"(X), "i"(X + 15), "i"(W),
+                 "i"(W + 3));
+}
+// v222..v255 = 0 except v222 / v223 = +1e30 (reference point -1e30: the first unit's row_fix always takes); the clobber
+// list makes the kernel descriptor count the registers
+__device__ __forceinline__ void p4_state_init() {
+  asm volatile(
+      "v_mov_b32 v222, 0x7149f2ca\n\tv_mov_b32 v223, 0x7149f2ca\n\t"
+      "v_mov_b32 v224, 0\n\tv_mov_b32 v225, 0\n\tv_mov_b32 v226, 0\n\tv_mov_b32 v227, 0\n\t"
+      "v_mov_b32 v228, 0\n\tv_mov_b32 v229, 0\n\tv_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\t"
+      "v_mov_b32 v232, 0\n\tv_mov_b32 v233, 0\n\tv_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\t"
+      "v_mov_b32 v236, 0\n\tv_mov_b32 v237, 0\n\tv_mov_b32 v238, 0\n\tv_mov_b32 v239, 0\n\t"
+      "v_mov_b32 v240, 0\n\tv_mov_b32 v241, 0\n\tv_mov_b32 v242, 0\n\tv_mov_b32 v243, 0\n\t"
+      "v_mov_b32 v244, 0\n\tv_mov_b32 v245, 0\n\tv_mov_b32 v246, 0\n\tv_mov_b32 v247, 0\n\t"
+      "v_mov_b32 v248, 0\n\tv_mov_b32 v249, 0\n\tv_mov_b32 v250, 0\n\tv_mov_b32 v251, 0\n\t"
+      "v_mov_b32 v252, 0\n\tv_mov_b32 v253, 0\n\tv_mov_b32 v254, 0\n\tv_mov_b32 v255, 0"
+      :
+      :
+      : "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235",
+        "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249",
+        "v250", "v251", "v252", "v253", "v254", "v255");
+}
+
 // rescale threshold of both kernels, exp2 domain (probabilities reach at most 2^PF_THR; 0 = the textbook rule)
 #ifndef PF_THR
 #define PF_THR 8
@@ -574,10 +623,6 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
 //     (tests/test_gpu_prefill.py runs every case on both).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-// tunable (A/B builds pass -D): VALU issue cycles of exp work dealt to one MFMA shadow
-#ifndef P4_CAP
-#define P4_CAP 24
-#endif
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -587,117 +632,78 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// P4_PRESCALE (A/B builds only, default 0 = exact): Q pre-multiplied by sm_scale * log2(e) and rounded to the model dtype,
-// the QK^T chains seeded with minus the running max - a logit then needs no VALU instruction before its exp2 (-32 of
-// ~190 VALU instructions per 32-key unit).  NOT the shipped path: the extra rounding of q * c moves a logit by
-// |logit| * 2^-9 / sqrt(3) (bf16) in the worst case, which breaks the reference's own tolerance on large-logit inputs
-// (tests/test_gpu_prefill.py::test_prefill_deterministic_and_large_logits: 1.0e-2 against 3e-3 in fp16); measured gain
-// in DESIGN.md section 3.2.
-#ifndef P4_PRESCALE
-#define P4_PRESCALE 0
-#endif
 // LDS fragment reads run P4_RA fragments ahead of the MFMAs that consume them (tunable, A/B builds)
 #ifndef P4_RA
 #define P4_RA 3
 #endif
-#if P4_PRESCALE
-// Exp work of a unit = 80 micro-ops (see `micro` in the kernel): item j (two logits of one query block) is exp2, exp2,
-// then - one item late - row-sum add, add, pack.  First micro-op of MFMA slot k: ops are dealt in order, a slot takes ops
-// while their issue costs (exp2 8 cycles, add / pack 4) fit P4_CAP; everything is placed by slot 24, where the second
-// half of P is first needed.
-constexpr int P4_NOPS = 80;
-__host__ __device__ constexpr int p4_op_cost(int g) {
-  if (g < 2) return 8;
-  const int t = g - 2, b = 1 + t / 5, r = t % 5;
-  return (b < 16 && r < 2) ? 8 : 4;
-}
-__host__ __device__ constexpr int p4_mb(int k) {
-  int g = 0;
-  for (int slot = 0; slot < k && slot < 24; ++slot) {
-    int used = 0;
-    while (g < P4_NOPS) {
-      const int cost = p4_op_cost(g);
-      if (used + cost > P4_CAP && slot != 23) break;
-      used += cost;
-      ++g;
-    }
+// issue cycles of exp work dealt to one MFMA shadow (A/B builds; the stream's 628 cycles fill 30 shadows at 21: the check's
+// ballot is then two shadows old when it is tested)
+#ifndef P4_CAP
+#define P4_CAP 21
+#endif
+
+// ---- the softmax work of one 32-key unit as ONE stream of 125 micro-ops, dealt evenly over 32 MFMA shadows ----------
+// Item j = 8 s2 + 4 qb + jp turns two logits of query block qb into two probabilities and one packed word: F0 F1 (the
+// logits into the exp2 domain, minus the row's reference point), E0 E1 (exp2), A0 A1 (sum into the unit's own row sums)
+// and PK (round both to the model dtype).  Stream order: the four FOLD ops (the PREVIOUS unit's sums into the running
+// sums l), item 0's F F E E, then for b = 1..15: F F of item b, A A PK of item b-1, E E of item b - an exp2 never directly
+// follows the fma that feeds it and an add never directly follows the exp2 it consumes - and, wound into the tail, the nine
+// ops of the CHECK (see the kernel: "optimistic probabilities"): five ORs over the first 15 words as soon as they exist,
+// A A PK of item 15, then the three ops that depend on its word.
+// The stream of unit u runs in the 16 shadows of phase B of unit u-1 (its logits S(u) are complete when phase A ends) and
+// the 16 shadows of phase A of unit u; the check is tested between the phases, before the first PV MFMA of the unit.
+// 32 shadows for 628 issue cycles (exp2 8, the others 4), ~20 per shadow: with the shadow's MFMA (8) and its one or two
+// LDS reads a shadow's issue work fits its 32 cycles of matrix pipe.  (Rounds 2-3 computed the exact row max of S(u)
+// first - the last 8 shadows of a unit - and dealt the exp work over 24 shadows at 24 cycles each: every one of those 24
+// over its budget, the other 8 under it; profiles/r03_prefill_slot_timeline.txt.)
+struct P4Op {
+  int kind, arg;
+};
+constexpr int P4_F0 = 0, P4_F1 = 1, P4_E0 = 2, P4_E1 = 3, P4_A0 = 4, P4_A1 = 5, P4_PK = 6, P4_CHK = 7, P4_FOLD = 8;
+constexpr int P4_NOPS = 125;
+struct P4Stream {
+  P4Op op[P4_NOPS];
+  int first[33];  // first op of stream shadow sl (0-15: phase B of the previous unit, 16-31: phase A)
+};
+constexpr P4Stream p4_build() {
+  P4Stream s{};
+  int n = 0;
+  for (int i = 0; i < 4; ++i) s.op[n++] = P4Op{P4_FOLD, i};
+  s.op[n++] = P4Op{P4_F0, 0};
+  s.op[n++] = P4Op{P4_F1, 0};
+  s.op[n++] = P4Op{P4_E0, 0};
+  s.op[n++] = P4Op{P4_E1, 0};
+  for (int b = 1; b < 16; ++b) {
+    s.op[n++] = P4Op{P4_F0, b};
+    s.op[n++] = P4Op{P4_F1, b};
+    s.op[n++] = P4Op{P4_A0, b - 1};
+    s.op[n++] = P4Op{P4_A1, b - 1};
+    s.op[n++] = P4Op{P4_PK, b - 1};
+    s.op[n++] = P4Op{P4_E0, b};
+    s.op[n++] = P4Op{P4_E1, b};
   }
-  return k >= 24 ? P4_NOPS : g;
-}
-static_assert(p4_mb(0) == 0 && p4_mb(24) == P4_NOPS, "exp micro-op placement");
-static_assert(p4_mb(15) >= 2 + 5 * 3 + 5 && p4_mb(16) >= 2 + 5 * 7 + 5 && p4_mb(23) >= 2 + 5 * 11 + 5,
-              "every group of packed words complete one slot before its first PV MFMA (see the exact variant)");
-#else
-// Exp work of a unit = 112 micro-ops (see `micro` in the kernel).  Item j (two logits of one query block): fma, fma (the
-// logits into the exp2 domain, minus the running max), exp2, exp2, row-sum add, add, pack.  Stream order: item 0's fma,
-// fma, exp2, exp2; then for b = 1..15: fma, fma of item b, add, add, pack of item b-1, exp2, exp2 of item b; then add,
-// add, pack of item 15 - an exp2 never directly follows the fma that feeds it and an add never directly follows the exp2
-// it consumes (hipcc otherwise pads those pairs with s_nop: 15 issue slots per unit in the first ordering).
-// First micro-op of MFMA slot k: ops are dealt in order, a slot takes ops while their issue costs (exp2 8 cycles, the
-// others 4) fit P4_CAP; everything is placed by slot 24, where the second half of P is first needed.
-// P4_MFMA_ROWSUM (A/B builds only, default 0): the row sums l from one extra MFMA per (query block, 16 keys) - an all-ones
-// A operand times the packed P fragment the PV MFMAs consume anyway - instead of 32 v_add_f32 per unit: +4 MFMAs for -32
-// VALU instructions per unit.  MEASURED SLOWER (7.89 ms against 7.56 ms at 32 K on one box, profiles/r03_prefill_ab.txt):
-// the stream is in-order, an MFMA issued behind another waits out the matrix pipe, and the 8 extra MFMAs per tile cost
-// more than the 64 adds they replace.  (It would also sum the probabilities as ROUNDED to the model dtype, where the
-// reference adds the fp32 values, :398-400.)
-#ifndef P4_MFMA_ROWSUM
-#define P4_MFMA_ROWSUM 0
-#endif
-#if P4_MFMA_ROWSUM
-constexpr int P4_NOPS = 80;  // item: fma, fma, exp2, exp2, pack; stream: F F E E (item 0), then F F P' E E per item, P' last
-__host__ __device__ constexpr int p4_op_kind(int g) {  // 0,1 fma  2,3 exp2  6 pack
-  if (g < 4) return g;
-  const int t = g - 4, b = 1 + t / 5, r = t % 5;
-  if (b == 16) return 6;
-  return r < 2 ? r : (r == 2 ? 6 : r - 1);
-}
-__host__ __device__ constexpr int p4_op_item(int g) {
-  if (g < 4) return 0;
-  const int t = g - 4, b = 1 + t / 5, r = t % 5;
-  if (b == 16) return 15;
-  return r == 2 ? b - 1 : b;
-}
-constexpr int P4_PACK_IDX(int item) { return 4 + 5 * item + 2; }  // stream index of item's pack
-#else
-constexpr int P4_NOPS = 112;
-__host__ __device__ constexpr int p4_op_kind(int g) {  // 0,1 fma  2,3 exp2  4,5 add  6 pack
-  if (g < 4) return g;
-  const int t = g - 4, b = 1 + t / 7, r = t % 7;
-  if (b == 16) return 4 + r;
-  return r < 2 ? r : (r < 5 ? r + 2 : r - 3);
-}
-__host__ __device__ constexpr int p4_op_item(int g) {
-  if (g < 4) return 0;
-  const int t = g - 4, b = 1 + t / 7, r = t % 7;
-  if (b == 16) return 15;
-  return (r >= 2 && r <= 4) ? b - 1 : b;
-}
-constexpr int P4_PACK_IDX(int item) { return 4 + 7 * item + 4; }
-#endif
-__host__ __device__ constexpr int p4_mb(int k) {
-  int g = 0;
-  for (int slot = 0; slot < k && slot < 24; ++slot) {
-    int used = 0;
-    while (g < P4_NOPS) {
-      const int kind = p4_op_kind(g);
-      const int cost = (kind == 2 || kind == 3) ? 8 : 4;
-      if (used + cost > P4_CAP && slot != 23) break;
-      used += cost;
-      ++g;
-    }
+  for (int i = 0; i < 4; ++i) s.op[n++] = P4Op{P4_CHK, i};  // words 0-11
+  s.op[n++] = P4Op{P4_A0, 15};
+  s.op[n++] = P4Op{P4_A1, 15};
+  s.op[n++] = P4Op{P4_CHK, 4};  // words 12-14
+  s.op[n++] = P4Op{P4_PK, 15};
+  for (int i = 5; i < 9; ++i) s.op[n++] = P4Op{P4_CHK, i};
+  // deal by issue cost
+  int cost = 0, sl = 0;
+  s.first[0] = 0;
+  for (int g = 0; g < P4_NOPS; ++g) {
+    int slot = cost / P4_CAP;
+    if (slot > 31) slot = 31;
+    while (sl < slot) s.first[++sl] = g;
+    cost += (s.op[g].kind == P4_E0 || s.op[g].kind == P4_E1) ? 8 : 4;
   }
-  return k >= 24 ? P4_NOPS : g;
+  while (sl < 32) s.first[++sl] = P4_NOPS;
+  return s;
 }
-static_assert(p4_mb(0) == 0 && p4_mb(24) == P4_NOPS, "exp micro-op placement");
-// The PV MFMAs are inline asm (pv_mfma): hipcc pads no VALU-write -> MFMA-read hazard for them, the placement does.  Slot
-// 16 + kk reads the packed words of query block kk & 1: items 0-3 / 4-7 (keys 0-15) from slot 16 / 17, items 8-11 / 12-15
-// (keys 16-31) from slot 24 / 25.  Each group's last pack must sit at least one whole slot (an MFMA and its fillers)
-// before its first reader:
-static_assert(p4_mb(15) > P4_PACK_IDX(3), "P of items 0-3 complete before slot 15 ends");
-static_assert(p4_mb(16) > P4_PACK_IDX(7), "P of items 4-7 complete before slot 16 ends");
-static_assert(p4_mb(23) > P4_PACK_IDX(11), "P of items 8-11 complete before slot 23 ends");
-#endif
+constexpr P4Stream P4S = p4_build();
+static_assert(P4S.first[32] == P4_NOPS && P4S.op[P4_NOPS - 1].kind == P4_CHK && P4S.op[P4_NOPS - 1].arg == 8, "stream");
+static_assert(P4S.first[16] > 4 + 4 + 7 * 3 + 5,
+              "the words of items 0-3 are packed in phase B: at least a whole phase before the MFMAs that read them");
 // -DCVLLM_PF_TS (debug builds of tools/dbg only): s_memrealtime at the phase boundaries of every workgroup
 #ifdef CVLLM_PF_TS
 __device__ unsigned long long g_pf_rt[8192 * 8];  // [workgroup][4 x s_memrealtime (100 MHz) | 4 x s_memtime (shader clock)]
@@ -713,13 +719,33 @@ __device__ unsigned long long g_pf_rt[8192 * 8];  // [workgroup][4 x s_memrealti
   do {           \
   } while (0)
 #endif
+// -DP4_TS_SLOT=k (debug builds of tools/dbg/slot_ts.sh only, k in 0..64): s_memtime at the entry of a steady-state tile, in
+// front of MFMA slot k of it (0-31 first unit, 32-63 second unit, 64 = before the barrier) and behind the barrier - the
+// per-slot timeline of one wave.  The stamps are inline asm, i.e. invisible to hipcc's wait-count pass: a counted LDS wait
+// that follows one may be a count too loose (results of such a build are not checked), the timing is what it is for.
+#ifdef P4_TS_SLOT
+__device__ unsigned long long g_p4_slot[8192 * 4];
+#ifndef P4_TS_WAVE
+#define P4_TS_WAVE 0
+#endif
+#define P4_STAMP(var) asm volatile("s_memtime %0" : "=s"(var))
+#define P4_SLOT_STAMP(slot)                          \
+  do {                                               \
+    if constexpr ((slot) == P4_TS_SLOT) P4_STAMP(ts_k); \
+  } while (0)
+#else
+#define P4_SLOT_STAMP(slot) \
+  do {                      \
+  } while (0)
+#endif
 constexpr int P4_THREADS = 256;
 constexpr int P4_SMEM = 3 * PF_KTILE + 3 * PF_VTILE;  // K and V triple-buffered: 113,664 B
 static_assert(P4_SMEM >= 4 * 64 * PF_OSTRIDE, "O staging image must fit");
 
 
 template <typename T, int G>
-__global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void prefill_attn_w4_kernel(
+__global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(P4_NUM_VGPR))) void
+prefill_attn_w4_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, int64_t sq_n,
     int64_t sk_n, int64_t sk_h, int64_t sv_n, int64_t sv_h, const uint16_t* __restrict__ kc,
     const uint16_t* __restrict__ vc, uint16_t* __restrict__ out, const int* __restrict__ seq_lens,
@@ -765,18 +791,6 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       uint4 t = valid_q ? *reinterpret_cast<const uint4*>(qp + 16 * s) : make_uint4(0, 0, 0, 0);
-#if P4_PRESCALE
-      // Q is pre-scaled by sm_scale * log2(e) ONCE (fp32 product rounded to the model dtype): the QK^T MFMAs then
-      // deliver the logits in the exp2 domain and - started from an accumulator that holds minus the running max, see
-      // `negm` - already relative to it, so a logit costs no VALU instruction before its exp2 (the reference scales the
-      // fp32 logit, sparse_varlen_kernel.py:360,385-392: the rounding of q * c to 16 bits moves a logit by ~1e-3 in the
-      // exp2 domain for bf16, below the rounding of P itself; the parity tests hold the reference's own tolerance).
-      const float2 a0 = unpack2<T>(t.x), a1 = unpack2<T>(t.y), a2 = unpack2<T>(t.z), a3 = unpack2<T>(t.w);
-      t.x = pack2<T>(a0.x * scale_log2e, a0.y * scale_log2e);
-      t.y = pack2<T>(a1.x * scale_log2e, a1.y * scale_log2e);
-      t.z = pack2<T>(a2.x * scale_log2e, a2.y * scale_log2e);
-      t.w = pack2<T>(a3.x * scale_log2e, a3.y * scale_log2e);
-#endif
       qf[qb][s] = __builtin_bit_cast(s16x8, t);
     }
   }
@@ -788,28 +802,24 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
   // ---- accumulators and LDS addressing ------------------------------------------------------------------------------
   acc_zero_all();  // O^T accumulators a[128:255] (see pv_mfma): block (qb, db) = a[128 + 16 (4 qb + db) .. + 15]
-#if P4_PRESCALE
-  // minus the running max (exp2 domain) of this lane's query, in all 16 registers of a block: the C operand every
-  // S = K Q^T chain starts from, so the chain ends in s*c - m (the attention-backward trick of the CDNA guide: row
-  // constants as the initial accumulator).  Rewritten only when a row's running max moves (rare, deferred rescale).
-  f32x16 negm[2];
-#else
-  float m_run[2] = {-1e30f, -1e30f};  // running max (exp2 domain), identical in lanes l and l^32; finite (see chain)
-#endif
-  // running sums of this lane's half of the keys, two per query block (even / odd logits of an item: consecutive adds
-  // never depend on each other); the probabilities are added straight into them
-  float l_run[2] = {0.f, 0.f}, l_run2[2] = {0.f, 0.f};
-#if P4_MFMA_ROWSUM && !P4_PRESCALE
-  // row sums by MFMA: D = ones(32 x 16) * P^T fragment + D puts a query's sum over the fragment's 16 keys (both lane
-  // halves) into every row of its column; only element 0 of a block is ever read (the rows never mix)
-  f32x16 lsum[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) lsum[qb][i] = 0.f;
-  const uint32_t one2 = pack2<T>(1.f, 1.f);
-  const s16x8 ones = __builtin_bit_cast(s16x8, make_uint4(one2, one2, one2, one2));
-#endif
+  // Optimistic probabilities.  A probability is exp2(s c - m_ref) with m_ref the row's REFERENCE POINT (identical in
+  // lanes l and l^32): the row max as of the last update plus P4_BIAS.  Everything accumulated (O, l) and every pending
+  // packed word is relative to m_ref; the row max of a unit is NOT computed on the common path.  Instead the packed
+  // words are checked before any MFMA consumes them: bit 14 of a bf16 / fp16 pattern is the top exponent bit, set iff
+  // the value is >= 2 (or inf / NaN), so OR-ing a unit half's 8 words and testing 0x40004000 tells whether some logit
+  // has climbed P4_BIAS + 1 above the row max of the last update (rare - the deferred rescale of the MI355X guide, T13,
+  // with the test moved from the logits to the probabilities: 6 VALU per check instead of ~15 for a row max).  Then, and
+  // only then (`row_fix`): exact row max of the unit, new m_ref, O and l rescaled, and the unit's stream replayed from
+  // its logits, which are still in registers.  The unit's own row sums (lu, lu2) are folded into l only after its second
+  // check: a probability that overflowed fp32 never reaches l, and one that overflowed the 16-bit type never reaches O.
+  // Probabilities are at most 2 and at least 2^-P4_BIAS at the old row max: bf16 keeps its relative precision at any
+  // magnitude, fp16 (normal down to 2^-14) takes a smaller bias.
+  constexpr float P4_BIAS = std::is_same<T, BF16>::value ? 7.f : 2.f;
+  // reference points, running sums l (two per query block: even / odd logits of an item, so that consecutive adds never
+  // depend on each other), the sums of the unit in flight and the packed words: asm-owned registers, see P4_VNM
+  p4_state_init();
+  uint32_t chk_a = 0, chk_b = 0, chk_c = 0, chk_d = 0, chk_e = 0;
+  unsigned long long chk_bal = 0;  // ballot of the unit's check (SGPR pair)
 
   const int gi = lane >> 4;
   const int li = lane & 15;
@@ -914,6 +924,21 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     else
       *reinterpret_cast<u32x4*>(vb + 16 * (i - 4) * PF_VSTR) = st[set][i];
   };
+#if defined(P4_NO_LSTORE) || defined(P4_LSTORE_CONST)  // timing-only A/B builds (wrong results): what the loop's LDS writes cost
+  const u32x4 lst_const = {(uint32_t)tid, (uint32_t)tid, (uint32_t)tid, (uint32_t)tid};
+  auto lstore_loop = [&](int set, int buf, int i) __attribute__((always_inline)) {
+#ifdef P4_LSTORE_CONST
+    char* kb = smem + buf * PF_KTILE + kst;
+    char* vb = smem + 3 * PF_KTILE + buf * PF_VTILE + vst;
+    if (i < 4)
+      *reinterpret_cast<u32x4*>(kb + 16 * i * PF_KSTR) = lst_const;
+    else
+      *reinterpret_cast<u32x4*>(vb + 16 * (i - 4) * PF_VSTR) = lst_const;
+#endif
+  };
+#else
+  auto lstore_loop = lstore_piece;
+#endif
 
   // The loop works in UNITS of 32 keys (half a staged tile).  For unit u (logits S(u), 16 registers per query block):
   //   phase A: 16 MFMAs  S(u+1) = K[unit u+1] Q^T      (every K fragment feeds both query blocks)
@@ -950,120 +975,126 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     return (const lds_char*)(uintptr_t)va;
   };
 
-  float mx_raw[2] = {-INFINITY, -INFINITY}, mx_new[2] = {0.f, 0.f};
-  u32x4 pw[2][2];   // P fragments of the current unit [query block][keys 0-15 / 16-31]
   // fragment rings: LDS reads run P4_RA fragments ahead of their MFMAs (lgkmcnt is a 4-bit counter: K reads + V
   // preloads + staging writes in flight must stay below 16)
   constexpr int RA = P4_RA, RING = P4_RA + 1;
   s16x8 kfr[RING], vfr[RING];
+#ifdef P4_TS_SLOT
+  unsigned long long ts_a = 0, ts_k = 0, ts_e = 0;
+#endif
 
-#if P4_PRESCALE
-  // The exp work of a unit as a list of 80 micro-ops, dealt to the unit's first 24 MFMA shadows by issue cost
-  // (p4_mb above).  Item j = 8 s2 + 4 qb + jp turns two logits (already s*c - m) into two probabilities and one packed
-  // word: ops 0-1 (exp2, exp2) of item b, then ops 2-4 (row-sum add, add, pack) of item b-1 - the adds one item late,
-  // or they would wait out the transcendental unit's latency.  Every op ends in an empty asm anchor: hipcc's IR passes
-  // otherwise sink it to its first use (the PV MFMA, the l update), out of its slot.
-  float mp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  auto micro = [&](const f32x16(&sc_)[2], int g) __attribute__((always_inline)) {
-    const int b = g < 2 ? 0 : 1 + (g - 2) / 5;
-    const int op = g < 2 ? g : (b == 16 ? 2 + (g - 2) % 5 : (g - 2) % 5);
-    const int j = op < 2 ? b : b - 1;
-    const int s2 = j >> 3, qb = (j >> 2) & 1, jp = j & 3;
-    if (op == 0) {
-      mp[j & 1][0] = __builtin_amdgcn_exp2f(sc_[qb][8 * s2 + 2 * jp]);
-      asm volatile("" : "+v"(mp[j & 1][0]));
-    } else if (op == 1) {
-      mp[j & 1][1] = __builtin_amdgcn_exp2f(sc_[qb][8 * s2 + 2 * jp + 1]);
-      asm volatile("" : "+v"(mp[j & 1][1]));
-    } else if (op == 2) {
-      l_run[qb] += mp[j & 1][0];  // the row sum is taken from the fp32 probabilities ...
-      asm volatile("" : "+v"(l_run[qb]));
-    } else if (op == 3) {
-      l_run2[qb] += mp[j & 1][1];
-      asm volatile("" : "+v"(l_run2[qb]));
-    } else {
-      uint32_t w = pack2<T>(mp[j & 1][0], mp[j & 1][1]);  // ... P itself is rounded to the model dtype (reference :398-400)
-      asm volatile("" : "+v"(w));
-      pw[qb][s2][jp] = w;
-    }
-  };
-#else
-  // The exp work of a unit as the list of 112 micro-ops described at p4_op_kind, dealt to the unit's first 24 MFMA
-  // shadows by issue cost (p4_mb).  Item j = 8 s2 + 4 qb + jp turns two logits into two probabilities and one packed
-  // word.  Every op ends in an empty asm anchor: hipcc's IR passes otherwise sink it to its first use (the PV MFMA, the l
-  // update), out of its slot.
+  // One micro-op of the stream (P4Op above).  The ops that touch the asm-owned state are asm statements; the others end in
+  // an empty asm anchor: hipcc's IR passes otherwise sink them to their first use, out of their shadow.  REPLAY (the rare
+  // path re-running a unit's stream from its logits): the same ops without the folds and the checks.
   float me0 = 0.f, me1 = 0.f, mp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  auto micro = [&](const f32x16(&sc_)[2], int g) __attribute__((always_inline)) {
-    const int op = p4_op_kind(g), j = p4_op_item(g);
-    const int s2 = j >> 3, qb = (j >> 2) & 1, jp = j & 3;
-    if (op == 0) {
-      me0 = fmaf(sc_[qb][8 * s2 + 2 * jp], scale_log2e, -m_run[qb]);
-      asm volatile("" : "+v"(me0));
-    } else if (op == 1) {
-      me1 = fmaf(sc_[qb][8 * s2 + 2 * jp + 1], scale_log2e, -m_run[qb]);
-      asm volatile("" : "+v"(me1));
-    } else if (op == 2) {
-      mp[j & 1][0] = __builtin_amdgcn_exp2f(me0);
-      asm volatile("" : "+v"(mp[j & 1][0]));
-    } else if (op == 3) {
-      mp[j & 1][1] = __builtin_amdgcn_exp2f(me1);
-      asm volatile("" : "+v"(mp[j & 1][1]));
-    } else if (op == 4) {
-      l_run[qb] += mp[j & 1][0];  // (P4_MFMA_ROWSUM = 0) the row sum is taken from the fp32 probabilities ...
-      asm volatile("" : "+v"(l_run[qb]));
-    } else if (op == 5) {
-      l_run2[qb] += mp[j & 1][1];
-      asm volatile("" : "+v"(l_run2[qb]));
+  auto micro = [&](const f32x16(&sc_)[2], auto g_c, auto par_c, auto replay_c) __attribute__((always_inline)) {
+    constexpr P4Op op = P4S.op[decltype(g_c)::value];
+    constexpr int kind = op.kind;
+    constexpr int PAR = decltype(par_c)::value;  // parity of the unit: which set of keys-0-15 words it writes
+    constexpr bool REPLAY = decltype(replay_c)::value;
+    if constexpr (kind == P4_FOLD) {
+      if constexpr (!REPLAY) {  // the previous unit's sums: not part of a replay
+        constexpr int qb = op.arg >> 1;
+        if constexpr ((op.arg & 1) == 0)
+          asm volatile("v_add_f32 v%c0, v%c0, v%c1" ::"i"(P4_VL + qb), "i"(P4_VLU + qb));
+        else
+          asm volatile("v_add_f32 v%c0, v%c0, v%c1" ::"i"(P4_VL2 + qb), "i"(P4_VLU2 + qb));
+      }
+    } else if constexpr (kind == P4_CHK) {
+      if constexpr (!REPLAY) {  // a replayed unit is not checked again
+        constexpr int st = op.arg;
+        auto or3w = [&](uint32_t& d, auto j0_c) __attribute__((always_inline)) {  // d = w[j0] | w[j0+1] | w[j0+2]
+          constexpr int j0 = decltype(j0_c)::value;
+          asm volatile("v_or3_b32 %0, v%c1, v%c2, v%c3"
+                       : "=v"(d)
+                       : "i"(p4_word_reg(PAR, j0)), "i"(p4_word_reg(PAR, j0 + 1)), "i"(p4_word_reg(PAR, j0 + 2)));
+        };
+        if constexpr (st == 0) {
+          or3w(chk_a, std::integral_constant<int, 0>{});
+        } else if constexpr (st == 1) {
+          or3w(chk_b, std::integral_constant<int, 3>{});
+        } else if constexpr (st == 2) {
+          or3w(chk_c, std::integral_constant<int, 6>{});
+        } else if constexpr (st == 3) {
+          or3w(chk_d, std::integral_constant<int, 9>{});
+        } else if constexpr (st == 4) {
+          or3w(chk_e, std::integral_constant<int, 12>{});
+        } else if constexpr (st == 5) {
+          asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(chk_a) : "v"(chk_b), "v"(chk_c));
+        } else if constexpr (st == 6) {
+          asm volatile("v_or3_b32 %0, %0, %1, v%c2" : "+v"(chk_d) : "v"(chk_e), "i"(p4_word_reg(PAR, 15)));
+        } else if constexpr (st == 7) {  // (a | d) & 0x40004000 in one v_bitop3 (truth table (S0 | S1) & S2 = 0xa8)
+          asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xa8" : "+v"(chk_a) : "v"(chk_d), "s"(0x40004000u));
+        } else {
+          chk_bal = __builtin_amdgcn_ballot_w64(chk_a != 0);
+          asm volatile("" : "+s"(chk_bal));
+        }
+      }
     } else {
-      uint32_t w = pack2<T>(mp[j & 1][0], mp[j & 1][1]);  // ... P itself is rounded to the model dtype (reference :398-400)
-      asm volatile("" : "+v"(w));
-      pw[qb][s2][jp] = w;
+      constexpr int j = op.arg;
+      constexpr int s2 = j >> 3, qb = (j >> 2) & 1, jp = j & 3;
+      if constexpr (kind == P4_F0) {
+        asm volatile("v_fma_f32 %0, %1, %2, v%c3" : "=v"(me0) : "v"(sc_[qb][8 * s2 + 2 * jp]), "s"(scale_log2e), "i"(P4_VNM + qb));
+      } else if constexpr (kind == P4_F1) {
+        asm volatile("v_fma_f32 %0, %1, %2, v%c3"
+                     : "=v"(me1)
+                     : "v"(sc_[qb][8 * s2 + 2 * jp + 1]), "s"(scale_log2e), "i"(P4_VNM + qb));
+      } else if constexpr (kind == P4_E0) {
+        mp[j & 1][0] = __builtin_amdgcn_exp2f(me0);
+        asm volatile("" : "+v"(mp[j & 1][0]));
+      } else if constexpr (kind == P4_E1) {
+        mp[j & 1][1] = __builtin_amdgcn_exp2f(me1);
+        asm volatile("" : "+v"(mp[j & 1][1]));
+      } else if constexpr (kind == P4_A0) {  // the row sum is taken from the fp32 probabilities ...
+        if constexpr (s2 == 0 && jp == 0)    // (the unit's first item of this query block starts its sums)
+          asm volatile("v_mov_b32 v%c0, %1" ::"i"(P4_VLU + qb), "v"(mp[j & 1][0]));
+        else
+          asm volatile("v_add_f32 v%c0, v%c0, %1" ::"i"(P4_VLU + qb), "v"(mp[j & 1][0]));
+      } else if constexpr (kind == P4_A1) {
+        if constexpr (s2 == 0 && jp == 0)
+          asm volatile("v_mov_b32 v%c0, %1" ::"i"(P4_VLU2 + qb), "v"(mp[j & 1][1]));
+        else
+          asm volatile("v_add_f32 v%c0, v%c0, %1" ::"i"(P4_VLU2 + qb), "v"(mp[j & 1][1]));
+      } else {  // ... P itself is rounded to the model dtype, round to nearest even (reference :398-400)
+        if constexpr (std::is_same<T, BF16>::value)
+          asm volatile("v_cvt_pk_bf16_f32 v%c0, %1, %2" ::"i"(p4_word_reg(PAR, j)), "v"(mp[j & 1][0]), "v"(mp[j & 1][1]));
+        else
+          asm volatile("v_cvt_pk_f16_f32 v%c0, %1, %2" ::"i"(p4_word_reg(PAR, j)), "v"(mp[j & 1][0]), "v"(mp[j & 1][1]));
+      }
     }
   };
-#endif
-  // row max of S over a 32-key block in four parts: three of max3 work, then the partner-lane exchange (its own part, a
-  // slot later: v_permlane32_swap needs its two source registers written two wait states earlier, and the copy that
-  // makes the second one sits at the end of part 2 - placed back to back hipcc pads them with s_nop 1)
-  float mxa = 0.f, mxb = 0.f, mxc[2] = {0.f, 0.f}, mxd[2] = {0.f, 0.f};
-  auto max_part = [&](const f32x16& a, int part, int qbi, float& out) __attribute__((always_inline)) {
-    if (part == 0) {
-      mxa = max3(a[0], a[1], a[2]), mxb = max3(a[3], a[4], a[5]);
-      mxa = max3(mxa, a[6], a[7]);
-    } else if (part == 1) {
-      mxb = max3(mxb, a[8], a[9]);
-      mxa = max3(mxa, a[10], a[11]), mxb = max3(mxb, a[12], a[13]);
-    } else if (part == 2) {
-      mxc[qbi] = max3(mxa, mxb, fmaxf(a[14], a[15]));
-      mxd[qbi] = mxc[qbi];
-      asm volatile("" : "+v"(mxc[qbi]), "+v"(mxd[qbi]));  // two registers, now
-    } else {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxc[qbi]), __float_as_uint(mxd[qbi]), false, false);
-      out = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
+  // RARE: a check found a probability >= 2 in the unit whose logits are sc_ (or this is the sequence's first unit).
+  // Exact row max of the unit (this lane's 16 keys, then the partner lane l ^ 32), and for every row that has climbed:
+  // reference point = row max + P4_BIAS, O and l scaled once by 2^(old - new).  Rows that have not climbed keep
+  // everything.  The caller replays the unit's stream afterwards.  A fully masked row has row max -inf: never taken.
+  auto row_fix = [&](const f32x16(&sc_)[2]) __attribute__((always_inline)) {
+    acc_settle();
+    static_for<0, 2>([&](auto qb_c) __attribute__((always_inline)) {
+      constexpr int qb = decltype(qb_c)::value;
+      const f32x16& a = sc_[qb];
+      float a0 = a[0], a3 = a[3];
+      asm volatile("" : "+v"(a0), "+v"(a3));  // keeps the max chain inside this (cold) block: hipcc otherwise speculates it
+      float x0 = max3(a0, a[1], a[2]), x1 = max3(a3, a[4], a[5]);
+      x0 = max3(x0, a[6], a[7]), x1 = max3(x1, a[8], a[9]);
+      x0 = max3(x0, a[10], a[11]), x1 = max3(x1, a[12], a[13]);
+      const float mx = max3(x0, x1, fmaxf(a[14], a[15]));
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      const float mxs = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2e;
+      float nm_old;  // minus the old reference point
+      asm volatile("v_mov_b32 %0, v%c1" : "=v"(nm_old) : "i"(P4_VNM + qb));
+      const bool take = mxs + nm_old > 0.5f;
+      const float nm_new = take ? -(mxs + P4_BIAS) : nm_old;
+      const float alpha = take ? __builtin_amdgcn_exp2f(nm_new - nm_old) : 1.f;  // 2^(old point - new point)
+      asm volatile("v_mov_b32 v%c0, %1\n\tv_mul_f32 v%c2, v%c2, %3\n\tv_mul_f32 v%c4, v%c4, %3" ::"i"(P4_VNM + qb),
+                   "v"(nm_new), "i"(P4_VL + qb), "v"(alpha), "i"(P4_VL2 + qb));
+      static_for<64 * qb, 64 * qb + 64>([&](auto r_c) __attribute__((always_inline)) {
+        constexpr int R = P4_ACC0 + decltype(r_c)::value;
+        acc_write<R>(acc_read<R>() * alpha);
+      });
+    });
+    asm volatile("s_nop 3" ::: "memory");  // v_accvgpr_write -> MFMA reads the register as its accumulator
   };
-#if P4_PRESCALE
-  // running-max bookkeeping of the NEXT unit for one query block: its logits are already relative to the running max,
-  // so their row max (mx_raw) IS the growth of the max.
-  // Deferred rescale (MI355X guide T13): the running max follows the row max only once it has grown by more than
-  // PF_THR in the exp2 domain, so probabilities reach at most 2^PF_THR instead of 1 - bf16 / fp16 keep their relative
-  // precision there and the fp32 sums have the headroom - and the 128-register rescale of O becomes rare (with an
-  // exact running max some row of a wave grows in every 5th unit of random data).  Every quantity at the old scale
-  // (O, l, the accumulator seed negm AND the next unit's logits, which were computed from the old seed; no P is pending
-  // at the decision) is moved exactly once.  PF_THR = 0 is the textbook rule.
-  auto chain = [&](int qb) __attribute__((always_inline)) { mx_new[qb] = mx_raw[qb]; };
-  // mask of unit (t, kb), rare: key kk of the unit is visible to this lane's query iff kk < lim.  Branch-free integer
-  // form (sign mask): a compare per logit would put dozens of lane masks into SGPR pairs at once.
-#else
-  // running-max bookkeeping of the NEXT unit for one query block (its logits' row max is in mx_raw).
-  // Deferred rescale (MI355X guide T13): the running max follows the row max only once it has grown by more than
-  // PF_THR in the exp2 domain, so probabilities reach at most 2^PF_THR instead of 1 - bf16 / fp16 keep their relative
-  // precision there and the fp32 sums have the headroom - and the 128-register rescale of O becomes rare (with an
-  // exact running max some row of a wave grows in every 5th unit of random data).  Every quantity at the old scale
-  // (O, l; no P is pending at the decision) is scaled exactly once.  PF_THR = 0 is the textbook rule.  The running
-  // max starts at a large negative FINITE value: no -inf special case on the common path (3 VALU per query block and
-  // unit), a row's first visible key always takes, and exp2(-inf c + 1e30) of a masked logit is still 0.
-  auto chain = [&](int qb) __attribute__((always_inline)) { mx_new[qb] = mx_raw[qb] * scale_log2e; };
-#endif
+
   // Which 32-key units need the mask (workgroup-uniform), as two scalar thresholds on the unit index u = 2 t + kb:
   // cached units from the first one that is not full (u >= Lc / 32) and appended units from the first one that reaches
   // past the tile's first query (32 ua + 31 > m0  <=>  ua >= (m0 + 1) / 32; a short last unit lies behind that one).
@@ -1087,146 +1118,79 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       }
     }
   };
-#if P4_PRESCALE
-  auto rescale_if_grew = [&](f32x16(&sn_)[2]) __attribute__((always_inline)) {
-    // a fully masked unit has mx_new = -inf: never taken
-    const bool t0 = mx_new[0] > (float)PF_THR, t1 = mx_new[1] > (float)PF_THR;
-    if (__builtin_amdgcn_ballot_w64(t0 || t1) != 0) {  // rare: some row of the wave moves its running max
-      acc_settle();
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const bool take = qb ? t1 : t0;
-        const float dm = take ? mx_new[qb] : 0.f;  // the running max grows by dm
-        const float alpha = __builtin_amdgcn_exp2f(-dm);
-        l_run[qb] *= alpha;
-        l_run2[qb] *= alpha;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          negm[qb][i] -= dm;
-          sn_[qb][i] -= dm;
-        }
-        if (qb == 0)
-          static_for<0, 64>([&](auto r_c) __attribute__((always_inline)) {
-            constexpr int R = P4_ACC0 + decltype(r_c)::value;
-            acc_write<R>(acc_read<R>() * alpha);
-          });
-        else
-          static_for<64, 128>([&](auto r_c) __attribute__((always_inline)) {
-            constexpr int R = P4_ACC0 + decltype(r_c)::value;
-            acc_write<R>(acc_read<R>() * alpha);
-          });
-      }
-      // the rewritten accumulators / seeds are MFMA operands next: VALU / v_accvgpr_write -> MFMA wait states
-      asm volatile("s_nop 3" ::: "memory");
-    }
-  };
 
+  // The stream of the unit (parity PAR) whose logits are sc_: the ops of stream shadow SL.
+  auto stream_ops = [&](const f32x16(&sc_)[2], auto sl_c, auto par_c) __attribute__((always_inline)) {
+    constexpr int SL = decltype(sl_c)::value;
+#ifdef P4_NO_STREAM  // timing-only A/B build (wrong results): the loop without its softmax work
+    if constexpr (SL == 0) asm volatile("" ::"v"(sc_[0]), "v"(sc_[1]));
 #else
-  auto rescale_if_grew = [&](f32x16(&)[2]) __attribute__((always_inline)) {
-    // a fully masked unit has mx_new = -inf: never taken
-    const bool t0 = mx_new[0] - m_run[0] > (float)PF_THR, t1 = mx_new[1] - m_run[1] > (float)PF_THR;
-    if ((__builtin_amdgcn_ballot_w64(t0) | __builtin_amdgcn_ballot_w64(t1)) != 0) {  // rare: a row moves its running max
-      acc_settle();
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const bool take = qb ? t1 : t0;
-        const float alpha = take ? __builtin_amdgcn_exp2f(m_run[qb] - mx_new[qb]) : 1.f;
-        m_run[qb] = take ? mx_new[qb] : m_run[qb];
-#if P4_MFMA_ROWSUM
-        lsum[qb][0] *= alpha;
-#else
-        l_run[qb] *= alpha;
-        l_run2[qb] *= alpha;
+    static_for<P4S.first[SL], P4S.first[SL + 1]>(
+        [&](auto g_c) __attribute__((always_inline)) { micro(sc_, g_c, par_c, std::false_type{}); });
 #endif
-        if (qb == 0)
-          static_for<0, 64>([&](auto r_c) __attribute__((always_inline)) {
-            constexpr int R = P4_ACC0 + decltype(r_c)::value;
-            acc_write<R>(acc_read<R>() * alpha);
-          });
-        else
-          static_for<64, 128>([&](auto r_c) __attribute__((always_inline)) {
-            constexpr int R = P4_ACC0 + decltype(r_c)::value;
-            acc_write<R>(acc_read<R>() * alpha);
-          });
-      }
-      asm volatile("s_nop 3" ::: "memory");  // v_accvgpr_write -> MFMA reads the register as its accumulator
-    }
   };
-
-#endif
-  // phase A of a unit: S(next) = K[next unit] Q^T beside the first ITEMS_A exp items of the current unit.
+  // (rare) the check fired: new reference points, then the unit's whole stream once more from its logits (without the
+  // four FOLD ops, which belong to the previous unit's sums, and without the check)
+  auto fix_and_replay = [&](const f32x16(&sc_)[2], auto par_c) __attribute__((always_inline)) {
+    row_fix(sc_);
+    static_for<4, P4_NOPS>([&](auto g_c) __attribute__((always_inline)) { micro(sc_, g_c, par_c, std::true_type{}); });
+    asm volatile("s_nop 1" ::: "memory");  // VALU-written packed words -> (asm) MFMA operand
+  };
+  // phase A of a unit of parity U (shadows 0-15): S(next) = K[next unit] Q^T beside the second half of the unit's stream.
   // Entry: kfr[0..RA-1] hold the first k-steps of the next unit's K block.  Exit: vfr[0..RA-1] hold this unit's first V
   // fragments.
-  auto phase_a = [&](const lds_char* kbp, const lds_char* vbp, const f32x16(&sc_)[2], f32x16(&sn_)[2], auto extra)
-                     __attribute__((always_inline)) {
+  auto phase_a = [&](auto u_c, const lds_char* kbp, const lds_char* vbp, const f32x16(&sc_)[2], f32x16(&sn_)[2],
+                     auto extra) __attribute__((always_inline)) {
     static_for<0, 16>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       constexpr int s = kk >> 1, qb = kk & 1;
+      P4_SLOT_STAMP(32 * decltype(u_c)::value + kk);
       if (qb == 0 && s + RA < KS) kfr[(s + RA) % RING] = k_read(kbp, s + RA);
       if (s == 0) {
-#if P4_PRESCALE
-        sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], negm[qb]);  // the chain starts at minus the running max
-#else
         f32x16 z;
 #pragma unroll
         for (int i = 0; i < 16; ++i) z[i] = 0.f;
         sn_[qb] = mfma32<T>(kfr[0], qf[qb][0], z);
-#endif
       } else {
         sn_[qb] = mfma32<T>(kfr[s % RING], qf[qb][s], sn_[qb]);
       }
-      static_for<p4_mb(kk), p4_mb(kk + 1)>([&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
+      stream_ops(sc_, std::integral_constant<int, 16 + kk>{}, u_c);
       if constexpr ((kk & 1) && kk >= 17 - 2 * RA) vfr[(kk - (17 - 2 * RA)) / 2] = v_read(vbp, (kk - (17 - 2 * RA)) / 2);
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
-  // phase B of a unit: O^T += V[unit]^T P^T beside the remaining exp items (first half), then the row max and the
-  // running-max bookkeeping of the next unit (second half).  (tn, kbn) = the next unit, whose logits are in sn_.
+  // phase B of a unit of parity U (shadows 16-31): first the unit's check (its stream is complete), then the mask of the
+  // next unit where it needs one; O^T += V[unit]^T P^T beside the first half of the NEXT unit's stream, whose logits
+  // are in sn_ ((tn, kbn) = that unit).
   // Exit: kfr[0..RA-1] hold the first k-steps of the K block at kbp_next (the unit after the next).
-  auto phase_b = [&](const lds_char* vbp, const lds_char* kbp_next, const f32x16(&sc_)[2], f32x16(&sn_)[2], int tn,
-                     int kbn, auto extra) __attribute__((always_inline)) {
-    static_for<0, 8>([&](auto kk_c) __attribute__((always_inline)) {
-      constexpr int kk = decltype(kk_c)::value;
-      constexpr int i = kk >> 1, qb = kk & 1;
-      if (qb == 0 && i + RA < 8) vfr[(i + RA) % RING] = v_read(vbp, i + RA);
-      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % RING], __builtin_bit_cast(s16x8, pw[qb][0]));
-#if P4_MFMA_ROWSUM && !P4_PRESCALE
-      if constexpr (kk < 2) lsum[qb] = mfma32<T>(ones, __builtin_bit_cast(s16x8, pw[qb][0]), lsum[qb]);
-#endif
-      static_for<p4_mb(16 + kk), p4_mb(16 + kk + 1)>(
-          [&](auto g_c) __attribute__((always_inline)) { micro(sc_, decltype(g_c)::value); });
-      if constexpr ((kk & 1) && kk >= 17 - 2 * RA) kfr[(kk - (17 - 2 * RA)) / 2] = k_read(kbp_next, (kk - (17 - 2 * RA)) / 2);
-      extra(kk);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if (2 * tn + kbn >= mask_lo) {
-      unit_mask(tn, kbn, sn_);
-      if (mask_lo < u_cend && 2 * tn + kbn + 1 >= u_cend) mask_lo = u_amask;
-    }
-    static_for<8, 16>([&](auto kk_c) __attribute__((always_inline)) {
-      constexpr int kk = decltype(kk_c)::value;
-      constexpr int i = kk >> 1, qb = kk & 1;
-      if (qb == 0 && i + RA < 8) vfr[(i + RA) % RING] = v_read(vbp, i + RA);
-      pv_mfma<T, P4_ACC0 + 16 * (4 * qb + (i & 3))>(vfr[i % RING], __builtin_bit_cast(s16x8, pw[qb][1]));
-#if P4_MFMA_ROWSUM && !P4_PRESCALE
-      if constexpr (kk < 10) lsum[qb] = mfma32<T>(ones, __builtin_bit_cast(s16x8, pw[qb][1]), lsum[qb]);
-#endif
-      if constexpr (kk < 14) max_part(sn_[(kk - 8) / 3], (kk - 8) % 3, (kk - 8) / 3, mx_raw[(kk - 8) / 3]);
-      if (kk == 11) max_part(sn_[0], 3, 0, mx_raw[0]);  // exchange of query block 0, one slot after its part 2
-      if (kk == 14) {
-        max_part(sn_[1], 3, 1, mx_raw[1]);
-        chain(0);
+  auto phase_b = [&](auto u_c, const lds_char* vbp, const lds_char* kbp_next, const f32x16(&sc_)[2], f32x16(&sn_)[2],
+                     int tn, int kbn, auto extra) __attribute__((always_inline)) {
+    constexpr int U = decltype(u_c)::value;
+    const bool need_mask = 2 * tn + kbn >= mask_lo;
+    if (__builtin_expect((chk_bal != 0) | need_mask, 0)) {  // one branch on the common path for both
+      if (chk_bal != 0) fix_and_replay(sc_, u_c);
+      if (need_mask) {
+        unit_mask(tn, kbn, sn_);
+        if (mask_lo < u_cend && 2 * tn + kbn + 1 >= u_cend) mask_lo = u_amask;
       }
-      if (kk == 15) chain(1);
-      // the next phase A's first RA K fragments, one per odd slot up to the last one
+    }
+    static_for<0, 16>([&](auto kk_c) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value;
+      constexpr int i = kk >> 1, qb = kk & 1;
+      P4_SLOT_STAMP(32 * U + 16 + kk);
+      if (qb == 0 && i + RA < 8) vfr[(i + RA) % RING] = v_read(vbp, i + RA);
+      pv_mfma_w<T, P4_ACC0 + 16 * (4 * qb + (i & 3)), (kk < 8 ? P4_VPW0 + 8 * U : P4_VPW1) + 4 * qb>(vfr[i % RING]);
+      stream_ops(sn_, kk_c, std::integral_constant<int, 1 - U>{});
+      // the next phase A's first RA K fragments, one per odd shadow up to the last one
       if constexpr ((kk & 1) && kk >= 17 - 2 * RA) kfr[(kk - (17 - 2 * RA)) / 2] = k_read(kbp_next, (kk - (17 - 2 * RA)) / 2);
       extra(kk);
       __builtin_amdgcn_sched_barrier(0);
     });
-    rescale_if_grew(sn_);
   };
   auto no_extra = [](int) {};
+  constexpr std::integral_constant<int, 0> U0{};
+  constexpr std::integral_constant<int, 1> U1{};
 
   // ---- prologue: tiles 0 and 1 staged, tiles 2 and 3 in flight; S(0, keys 0-31) and its bookkeeping unpipelined ----
   // A tile's loads are issued two iterations before its LDS writes (two register sets): every workgroup of a
@@ -1258,25 +1222,10 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       unit_mask(0, 0, sX);
       if (mask_lo < u_cend && 1 >= u_cend) mask_lo = u_amask;
     }
-#pragma unroll
-    for (int part = 0; part < 8; ++part) max_part(sX[part / 4], part % 4, part / 4, mx_raw[part / 4]);
-#if P4_PRESCALE
-    // the first unit's row max IS the initial running max (O and l are still zero: nothing to rescale); every query
-    // sees at least one key of its first unit, a row without one (never stored) starts at 0
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const float m_first = mx_raw[qb] == -INFINITY ? 0.f : mx_raw[qb];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        negm[qb][i] = -m_first;
-        sX[qb][i] -= m_first;
-      }
-    }
-#else
-    chain(0);
-    chain(1);
-    rescale_if_grew(sX);  // O and l are still zero: this only moves the running max
-#endif
+    // the first unit sets the reference points (O and l are still zero: nothing else moves; every query sees key 0 of
+    // its sequence, so every row takes), then runs the first half of its stream outside any MFMA shadow
+    row_fix(sX);
+    static_for<0, 16>([&](auto sl_c) __attribute__((always_inline)) { stream_ops(sX, sl_c, std::integral_constant<int, 0>{}); });
     const lds_char* kb1 = k_ptr(0, 1);
 #pragma unroll
     for (int f = 0; f < RA; ++f) kfr[f] = k_read(kb1, f);
@@ -1296,21 +1245,35 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     constexpr bool APP = decltype(app_c)::value;  // every tile loaded from here on is an appended one
     const int nxt = cur == 2 ? 0 : cur + 1;   // (t + 1) % 3
     const int nxt2 = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
+#ifdef P4_TS_SLOT
+    P4_STAMP(ts_a);
+#endif
     // unit (t, keys 0-31): logits in sX; the next unit is (t, keys 32-63), then (t + 1, keys 0-31)
     {
       const lds_char* vbp = v_ptr(cur, 0);
-      phase_a(k_ptr(cur, 1), vbp, sX, sY, no_extra);
-      phase_b(vbp, k_ptr(nxt, 0), sX, sY, t, 1, no_extra);
+      phase_a(U0, k_ptr(cur, 1), vbp, sX, sY, [&](int kk) __attribute__((always_inline)) {
+        if (kk == 5) lstore_loop(SET, nxt2, 0);
+        if (kk == 11) lstore_loop(SET, nxt2, 1);
+      });
+      phase_b(U0, vbp, k_ptr(nxt, 0), sX, sY, t, 1, [&](int kk) __attribute__((always_inline)) {
+        if (kk == 5) lstore_loop(SET, nxt2, 2);
+        if (kk == 11) lstore_loop(SET, nxt2, 3);
+      });
     }
     // unit (t, keys 32-63): logits in sY.  On the last tile S(t + 1) is computed from a stale K tile and never used.
-    // Its shadows also carry the staging: tile t+2 goes from its register set to LDS during phase A, the loads of
-    // tile t+4 into the same set are issued during phase B.
+    // The staging rides along: the eight LDS writes of tile t+2 (buffer (t+2) % 3 = the one tile t-1 left at the last
+    // barrier) are spread over the tile, two per phase - eight in one phase cost that phase 330 cycles, the LDS pipe being
+    // ~60 % busy with fragment reads as it is (profiles/r03_prefill_slot_timeline.txt) - and the loads of tile t+4 into the
+    // same register set follow in the last phase, each after the write of its piece.
     {
       const lds_char* vbp = v_ptr(cur, 1);
-      phase_a(k_ptr(nxt, 0), vbp, sY, sX, [&](int kk) __attribute__((always_inline)) {
-        if (kk & 1) lstore_piece(SET, nxt2, kk >> 1);
+      phase_a(U1, k_ptr(nxt, 0), vbp, sY, sX, [&](int kk) __attribute__((always_inline)) {
+        if (kk == 5) lstore_loop(SET, nxt2, 4);
+        if (kk == 11) lstore_loop(SET, nxt2, 5);
       });
-      phase_b(vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, [&](int kk) __attribute__((always_inline)) {
+      phase_b(U1, vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, [&](int kk) __attribute__((always_inline)) {
+        if (kk == 0) lstore_loop(SET, nxt2, 6);
+        if (kk == 2) lstore_loop(SET, nxt2, 7);
         if constexpr (APP) {
           if (kk == 0) tile_desc_app();
           if (kk & 1) gload_piece_app(SET, kk >> 1);
@@ -1320,8 +1283,22 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       });
     }
+    P4_SLOT_STAMP(64);
 #ifndef P4_NO_BARRIER  // timing-only A/B build (wrong results): what the one barrier per tile costs
     lds_barrier();
+#endif
+#ifdef P4_TS_SLOT
+    P4_STAMP(ts_e);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // s_memtime lands in its SGPR pair asynchronously: the pairs must stay reserved until the wait above, in EVERY copy
+    // of the tile body (a dead stamp's pair would otherwise be reused at once and overwritten late by the counter)
+    asm volatile("" ::"s"(ts_a), "s"(ts_k), "s"(ts_e));
+    if (t == 16 && tid == P4_TS_WAVE * 64 && bid < 8192) {
+      g_p4_slot[bid * 4 + 0] = ts_a;
+      g_p4_slot[bid * 4 + 1] = ts_k;
+      g_p4_slot[bid * 4 + 2] = ts_e;
+      g_p4_slot[bid * 4 + 3] = ntiles;
+    }
 #endif
   };
   // Pairs of tiles, then an odd last one: with the second body under an `if` inside the loop, hipcc's wait-count
@@ -1355,12 +1332,9 @@ __global__ __launch_bounds__(P4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   char* ob = smem + wave * (64 * PF_OSTRIDE);
   static_for<0, 2>([&](auto qb_c) __attribute__((always_inline)) {
     constexpr int qb = decltype(qb_c)::value;
-#if P4_MFMA_ROWSUM && !P4_PRESCALE
-    const float l_tot = lsum[qb][0];  // the MFMA already summed both lane halves' keys
-#else
-    const float l_lane = l_run[qb] + l_run2[qb];
+    float l_lane;
+    asm volatile("v_add_f32 %0, v%c1, v%c2" : "=v"(l_lane) : "i"(P4_VL + qb), "i"(P4_VL2 + qb));
     const float l_tot = l_lane + __shfl_xor(l_lane, 32, 64);
-#endif
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     static_for<0, 16>([&](auto j_c) __attribute__((always_inline)) {
       constexpr int db = decltype(j_c)::value >> 2, i4 = decltype(j_c)::value & 3;
@@ -1463,6 +1437,12 @@ extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, i
   if (sk_n < 0 || sv_n < 0 || sk_n > 0x7fffffff || sv_n > 0x7fffffff) return CVLLM_ERR_SHAPE;  // 32-bit row strides in the kernel
   const int G = HQ / HKV;
   hipStream_t st = (hipStream_t)stream;
+#ifdef P4_TS_SLOT  // debug build: the one instantiation the stamps are read from
+  if (dtype != CVLLM_BF16 || D != 128 || G != 4) return CVLLM_ERR_SHAPE;
+  return launch_prefill<BF16, 128, 4>(q, k, v, sq_n, sk_n, sk_h, sv_n, sv_h, k_cache, v_cache, out, seq_lens_bh, page_table,
+                                      batch_mapping, cu_seqlens_q, B, max_seqlen_q, HKV, page_size, n_logical_pages_max,
+                                      sm_scale, st);
+#else
 #define PF_D(T_, D_)                                                                                              \
   return prefill_dispatch_g<T_, D_>(G, q, k, v, sq_n, sk_n, sk_h, sv_n, sv_h, k_cache, v_cache, out, seq_lens_bh, \
                                     page_table, batch_mapping, cu_seqlens_q, B, max_seqlen_q, HKV, page_size,     \
@@ -1476,8 +1456,15 @@ extern "C" int cvllm_prefill_attn(const void* q, const void* k, const void* v, i
   }
 #undef PF_D
   return CVLLM_ERR_SHAPE;
+#endif
 }
 
+#ifdef P4_TS_SLOT
+extern "C" void cvllm_debug_prefill_slot_stamps(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cvllm::g_p4_slot), sizeof(unsigned long long) * 8192 * 4);
+}
+#endif
 #ifdef CVLLM_PF_TS
 extern "C" void cvllm_debug_prefill_stamps(unsigned long long* out) {
   (void)hipDeviceSynchronize();

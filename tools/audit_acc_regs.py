@@ -1,9 +1,10 @@
-"""Audit of the asm-owned accumulator registers of prefill_attn_w4_kernel (csrc/prefill_attn.hip, pv_mfma).
+"""Audit of the asm-owned registers of prefill_attn_w4_kernel (csrc/prefill_attn.hip: pv_mfma_w, P4_VNM ...).
 
-The kernel keeps its 128 output accumulators in a[128:255] by naming them literally inside inline asm; the compiler must
-never allocate those registers itself.  This script reads the assembly hipcc emits for the file (-S) and fails if any
-instruction OUTSIDE an ;;#ASMSTART / ;;#ASMEND pair of such a kernel names an AGPR >= 128, if the kernel spills, or if
-it uses scratch.  build.py runs it whenever prefill_attn.hip is rebuilt.
+The kernel keeps its 128 output accumulators in a[128:255] and its softmax state (reference points, row sums, packed P
+words) in v[222:255] by naming them literally inside inline asm; the compiler must never allocate those registers itself.
+This script reads the assembly hipcc emits for the file (-S) and fails if any instruction OUTSIDE an ;;#ASMSTART /
+;;#ASMEND pair of such a kernel names an AGPR >= 128 or an arch VGPR >= 222, if the kernel spills, or if it uses
+scratch.  build.py runs it whenever prefill_attn.hip is rebuilt.
 
     python tools/audit_acc_regs.py file.s
 """
@@ -11,6 +12,7 @@ import re
 import sys
 
 ACC0 = 128
+VGPR0 = 222
 
 
 def audit(path: str) -> list:
@@ -34,6 +36,10 @@ def audit(path: str) -> list:
                 hi = int(r.group(2)) if r.group(2) is not None else int(r.group(3))
                 if hi >= ACC0:
                     problems.append(f"{name}: compiler instruction touches an asm-owned AGPR: {t}")
+            for r in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", code):
+                hi = int(r.group(2)) if r.group(2) is not None else int(r.group(3))
+                if hi >= VGPR0:
+                    problems.append(f"{name}: compiler instruction touches an asm-owned VGPR: {t}")
     for m in re.finditer(r"\.amdhsa_kernel (_ZN5cvllm22prefill_attn_w4_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", m.group(2)).group(1))
         if scratch != 0:
