@@ -739,8 +739,25 @@ __device__ unsigned long long g_p4_slot[8192 * 4];
   } while (0)
 #endif
 constexpr int P4_THREADS = 256;
-constexpr int P4_SMEM = 3 * PF_KTILE + 3 * PF_VTILE;  // K and V triple-buffered: 113,664 B
-static_assert(P4_SMEM >= 4 * 64 * PF_OSTRIDE, "O staging image must fit");
+// K / V tiles reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write - the eight
+// ds_write_b128 of a tile cost a wave ~290 of its ~2,950 cycles per tile, profiles/r03_prefill_slot_timeline.txt).  A DMA
+// instruction writes 64 x 16 B to CONSECUTIVE LDS bytes, so the images are in READ ORDER: the 1 KB a ds_read_b128 of K
+// k-step s (or the two ds_read_b64_tr_b16 of a V fragment) takes is one contiguous block, lane-linear - conflict free,
+// every fragment address = one lane-constant VGPR + an immediate - and each lane's SOURCE offset picks the 16 B that
+// belong there.  Four buffers of K and of V (128 KB): the DMAs of tile t+3 are issued during tile t and waited for
+// (counted vmcnt) at the end of tile t+1.
+#ifndef P4_DMA
+#define P4_DMA 1
+#endif
+#if P4_DMA
+constexpr int P4_NBUF = 4;
+constexpr int P4_KTILE = PF_KT * 256, P4_VTILE = PF_KT * 256;  // 16 KB each, no padding
+#else
+constexpr int P4_NBUF = 3;
+constexpr int P4_KTILE = PF_KTILE, P4_VTILE = PF_VTILE;
+#endif
+constexpr int P4_SMEM = P4_NBUF * (P4_KTILE + P4_VTILE);  // DMA: 131,072 B; register staging: 113,664 B
+static_assert(P4_SMEM >= 4 * 64 * PF_OSTRIDE && P4_SMEM <= 160 * 1024, "O staging image must fit");
 
 
 template <typename T, int G>
@@ -819,18 +836,135 @@ prefill_attn_w4_kernel(
   // depend on each other), the sums of the unit in flight and the packed words: asm-owned registers, see P4_VNM
   p4_state_init();
   uint32_t chk_a = 0, chk_b = 0, chk_c = 0, chk_d = 0, chk_e = 0;
-  unsigned long long chk_bal = 0;  // ballot of the unit's check (SGPR pair)
+  unsigned long long chk_bal = 0;    // ballot of the unit's check (SGPR pair)
+  unsigned long long rare_flag = 0;  // ... or-ed with "the next unit needs the mask": what the phase boundary branches on
 
   const int gi = lane >> 4;
   const int li = lane & 15;
   const int tq = li >> 2, tp = li & 3;
+#if P4_DMA
+  const uint32_t k_lane = lane * 16;  // read-order images: lane-linear
+  const uint32_t v_lane = lane * 8;
+  (void)gi, (void)tq, (void)tp;
+#else
   const uint32_t k_lane = r * PF_KSTR + h * 16;
   const uint32_t v_lane = (4 * (gi >> 1) + tq) * PF_VSTR + (gi & 1) * 32 + tp * 8;
+#endif
   typedef __attribute__((address_space(3))) char lds_char;
   typedef __attribute__((address_space(3))) s16x8 lds_s16x8;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)smem;
 
+#if P4_DMA
+  // ---- staging by LDS-DMA ---------------------------------------------------------------------------------------------
+  // A tile = 16 K blocks + 16 V blocks of 1 KB; wave w issues blocks 4w .. 4w+3 of each (four K and four V DMAs per tile).
+  //   K block (kb, s) = bytes of ds_read_b128 for k-step s of unit kb: lane L holds key 32 kb + (L & 31), 16-byte chunk
+  //                     2 s + (L >> 5) of its row;  block index 8 kb + s.
+  //   V block (kb, i) = bytes of the two ds_read_b64_tr_b16 of fragment i = 4 s2 + db of unit kb (lo | hi, 512 B each):
+  //                     DMA lane L covers the 8-byte pieces of read lanes 2 m and 2 m + 1 (m = L & 31) of the lo (L < 32)
+  //                     or hi read - 16 contiguous bytes of key 32 kb + 16 s2 + 8 hi + 4 (m >> 4) + ((m & 7) >> 1) at column
+  //                     64 db + 32 ((m >> 3) & 1) + 16 (m & 1);  block index 8 kb + i.
+  // The tile's base and valid byte count sit in the resource descriptor, the lane's (row, column) in loop-invariant VGPR
+  // offsets, one set per layout (cached rows are D elements apart, appended rows sk_n / sv_n): rows past the end of the
+  // tile are out of range and arrive as zeros.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  uint32_t voffKc[4], voffKa[4], voffVc[4], voffVa[4];
+  {
+    const int wkb = wave >> 1, w1 = wave & 1, m = lane & 31, hi = lane >> 5;
+    const uint32_t krow = 32 * wkb + m;
+    const uint32_t vrow = 32 * wkb + 16 * w1 + 8 * hi + 4 * (m >> 4) + ((m & 7) >> 1);
+    const uint32_t vcol = 32 * ((m >> 3) & 1) + 16 * (m & 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t kcol = (2 * (4 * w1 + j) + hi) * 16;
+      voffKc[j] = krow * (D * 2) + kcol;
+      voffKa[j] = krow * (uint32_t)sk_n * 2 + kcol;
+      voffVc[j] = vrow * (D * 2) + 64 * j + vcol;
+      voffVa[j] = vrow * (uint32_t)sv_n * 2 + 64 * j + vcol;
+    }
+  }
+  int ld_pi = 0, ld_po = 0;
+  int ld_pg = (ntc > 0) ? pt[0] : 0;
+  bool ld_app = false;  // layout of the tile whose descriptors are current (workgroup-uniform)
+  u32x4 rk, rv;         // buffer resource descriptors (SGPRs): base, stride 0, valid bytes, raw-buffer flags
+  auto mk_rsrc = [&](const uint16_t* p, int nbytes) __attribute__((always_inline)) {
+    const uint64_t a = (uint64_t)p;
+    const u32x4 d = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)nbytes, 0x00020000u};
+    return d;
+  };
+  // running state of the two kinds: the current page's base (cached) / the next tile's base and the valid bytes from
+  // there to the end of the visible rows (appended) - a tile costs two 64-bit adds and a subtract, not a 64-bit multiply
+  const uint16_t* c_kp = kc + (int64_t)ld_pg * PS * D;
+  const uint16_t* c_vp = vc + (int64_t)ld_pg * PS * D;
+  const uint16_t* a_kp = k + (int64_t)s0 * sk_n + (int64_t)g * sk_h;
+  const uint16_t* a_vp = v + (int64_t)s0 * sv_n + (int64_t)g * sv_h;
+  int a_remk = la_vis > 0 ? (int)(((uint32_t)(la_vis - 1) * (uint32_t)sk_n + D) * 2) : 0;
+  int a_remv = la_vis > 0 ? (int)(((uint32_t)(la_vis - 1) * (uint32_t)sv_n + D) * 2) : 0;
+  const int a_stepk = PF_KT * (int)sk_n, a_stepv = PF_KT * (int)sv_n;  // elements per appended tile
+  auto tile_desc_app = [&]() __attribute__((always_inline)) {
+    // valid bytes reach to the END of the visible rows (the row offsets cover 64 rows anyway); tiles past the last one
+    // have nothing left: every row out of range, nothing is fetched
+    rk = mk_rsrc(a_kp, max(a_remk, 0));
+    rv = mk_rsrc(a_vp, max(a_remv, 0));
+    a_kp += a_stepk;
+    a_vp += a_stepv;
+    a_remk -= 2 * a_stepk;
+    a_remv -= 2 * a_stepv;
+  };
+  auto tile_desc = [&](int tt) __attribute__((always_inline)) {
+    ld_app = tt >= ntc;
+    if (!ld_app) {
+      const int count = min(PF_KT, Lc - tt * PF_KT);  // > 0
+      rk = mk_rsrc(c_kp + ld_po * D, count * D * 2);
+      rv = mk_rsrc(c_vp + ld_po * D, count * D * 2);
+      ld_po += PF_KT;
+      if (ld_po >= PS) {
+        ld_po = 0;
+        ld_pi += 1;
+        ld_pg = pt[min(ld_pi, NLP - 1)];
+        c_kp = kc + (int64_t)ld_pg * PS * D;  // int64 row offset (reference :371)
+        c_vp = vc + (int64_t)ld_pg * PS * D;
+      }
+    } else {
+      tile_desc_app();
+    }
+  };
+  // one DMA: 64 lanes x 16 B from rsrc + voff to LDS bytes [dst + 1024 j, + 1024).  Inline asm: M0 (the LDS base of the
+  // DMA) is written in the statement that uses it, and hipcc's wait-count pass does not see the instruction - it would
+  // otherwise drain vmcnt to 0 in front of every ds_read that may alias the destination.  The waits are placed by hand
+  // (dma_wait).
+  auto dma16 = [&](const u32x4& rs, uint32_t voff, uint32_t dst, auto j_c) __attribute__((always_inline)) {
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(dst), "v"(voff), "s"(rs), "i"(1024 * decltype(j_c)::value)
+                 : "memory", "scc");
+  };
+  // LDS byte address of the wave's first K / V block of buffer `buf`
+  auto dma_dst_k = [&](int buf) __attribute__((always_inline)) { return lds0 + (uint32_t)(buf * P4_KTILE + wv * 4096); };
+  auto dma_dst_v = [&](int buf) __attribute__((always_inline)) {
+    return lds0 + (uint32_t)(P4_NBUF * P4_KTILE + buf * P4_VTILE + wv * 4096);
+  };
+  auto dma_k = [&](uint32_t dst, auto j_c, auto app_c) __attribute__((always_inline)) {
+    constexpr int j = decltype(j_c)::value;
+    if constexpr (decltype(app_c)::value)
+      dma16(rk, voffKa[j], dst, j_c);
+    else
+    {
+      const uint32_t oa = voffKa[j], oc = voffKc[j];
+      dma16(rk, ld_app ? oa : oc, dst, j_c);
+    }
+  };
+  auto dma_v = [&](uint32_t dst, auto j_c, auto app_c) __attribute__((always_inline)) {
+    constexpr int j = decltype(j_c)::value;
+    if constexpr (decltype(app_c)::value)
+      dma16(rv, voffVa[j], dst, j_c);
+    else
+    {
+      const uint32_t oa = voffVa[j], oc = voffVc[j];
+      dma16(rv, ld_app ? oa : oc, dst, j_c);
+    }
+  };
+#else
   // ---- staging: thread -> rows srow + 16 i (i = 0..3), 16-byte chunk sch of a K and of a V tile -------------------
   // Buffer loads: the tile's base and size sit in the resource descriptor (SGPRs), the row block in the scalar offset,
   // the lane's (row, chunk) in ONE loop-invariant VGPR - no per-load address arithmetic on the VALU; rows past the end
@@ -940,6 +1074,8 @@ prefill_attn_w4_kernel(
   auto lstore_loop = lstore_piece;
 #endif
 
+#endif
+
   // The loop works in UNITS of 32 keys (half a staged tile).  For unit u (logits S(u), 16 registers per query block):
   //   phase A: 16 MFMAs  S(u+1) = K[unit u+1] Q^T      (every K fragment feeds both query blocks)
   //   phase B: 16 MFMAs  O^T   += V[unit u]^T P(u)^T   (every V fragment feeds both query blocks)
@@ -954,23 +1090,32 @@ prefill_attn_w4_kernel(
   // registers (32) the arch VGPRs hold everything the VALU touches (this file is built with -amdgpu-mfma-vgpr-form:
   // MFMA results in arch VGPRs, no v_accvgpr_read in front of the softmax) and nothing spills.  K and V are
   // triple-buffered: S(t+1) of a unit is computed in the same iteration that writes tile t+2.
+#if P4_DMA
+  constexpr int K_STEP = 1024, K_UNIT = 8192, V_FRAG = 1024, V_HI = 512, V_UNIT = 8192;
+#else
+  constexpr int K_STEP = 32, K_UNIT = 32 * PF_KSTR, V_UNIT = 32 * PF_VSTR;
+#endif
   auto k_read = [&](const lds_char* kbp, int s) __attribute__((always_inline)) {
-    return *reinterpret_cast<const lds_s16x8*>(kbp + 32 * s);
+    return *reinterpret_cast<const lds_s16x8*>(kbp + K_STEP * s);
   };
   auto v_read = [&](const lds_char* vbp, int i) __attribute__((always_inline)) {  // i = 4 * s2 + db
-    const uint32_t a0 = (i >> 2) * 16 * PF_VSTR + 64 * (i & 3);
+#if P4_DMA
+    const uint32_t a0 = V_FRAG * i, a1 = a0 + V_HI;
+#else
+    const uint32_t a0 = (i >> 2) * 16 * PF_VSTR + 64 * (i & 3), a1 = a0 + 8 * PF_VSTR;
+#endif
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbp + a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbp + a0 + 8 * PF_VSTR));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbp + a1));
     const s16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return a;
   };
   auto k_ptr = [&](int buf, int kb) __attribute__((always_inline)) {
-    uint32_t ka = lds0 + buf * PF_KTILE + kb * (32 * PF_KSTR) + k_lane;
+    uint32_t ka = lds0 + buf * P4_KTILE + kb * K_UNIT + k_lane;
     asm volatile("" : "+v"(ka));  // one lane-constant VGPR + immediates for every read of the unit
     return (const lds_char*)(uintptr_t)ka;
   };
   auto v_ptr = [&](int buf, int kb) __attribute__((always_inline)) {
-    uint32_t va = lds0 + 3 * PF_KTILE + buf * PF_VTILE + kb * (32 * PF_VSTR) + v_lane;
+    uint32_t va = lds0 + P4_NBUF * P4_KTILE + buf * P4_VTILE + kb * V_UNIT + v_lane;
     asm volatile("" : "+v"(va));
     return (const lds_char*)(uintptr_t)va;
   };
@@ -1040,11 +1185,12 @@ prefill_attn_w4_kernel(
                      : "=v"(me1)
                      : "v"(sc_[qb][8 * s2 + 2 * jp + 1]), "s"(scale_log2e), "i"(P4_VNM + qb));
       } else if constexpr (kind == P4_E0) {
-        mp[j & 1][0] = __builtin_amdgcn_exp2f(me0);
-        asm volatile("" : "+v"(mp[j & 1][0]));
+        // asm like its neighbours: between a compiler-emitted v_exp and an asm statement that reads its result hipcc's
+        // hazard recogniser counts the asm statements in between as no wait states and pads with s_nop (7 per unit); the
+        // stream order itself keeps three instructions between an exp2 and its first reader
+        asm volatile("v_exp_f32 %0, %1" : "=v"(mp[j & 1][0]) : "v"(me0));
       } else if constexpr (kind == P4_E1) {
-        mp[j & 1][1] = __builtin_amdgcn_exp2f(me1);
-        asm volatile("" : "+v"(mp[j & 1][1]));
+        asm volatile("v_exp_f32 %0, %1" : "=v"(mp[j & 1][1]) : "v"(me1));
       } else if constexpr (kind == P4_A0) {  // the row sum is taken from the fp32 probabilities ...
         if constexpr (s2 == 0 && jp == 0)    // (the unit's first item of this query block starts its sums)
           asm volatile("v_mov_b32 v%c0, %1" ::"i"(P4_VLU + qb), "v"(mp[j & 1][0]));
@@ -1140,7 +1286,7 @@ prefill_attn_w4_kernel(
   // Entry: kfr[0..RA-1] hold the first k-steps of the next unit's K block.  Exit: vfr[0..RA-1] hold this unit's first V
   // fragments.
   auto phase_a = [&](auto u_c, const lds_char* kbp, const lds_char* vbp, const f32x16(&sc_)[2], f32x16(&sn_)[2],
-                     auto extra) __attribute__((always_inline)) {
+                     unsigned long long need_mask, auto extra) __attribute__((always_inline)) {
     static_for<0, 16>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       constexpr int s = kk >> 1, qb = kk & 1;
@@ -1155,8 +1301,12 @@ prefill_attn_w4_kernel(
         sn_[qb] = mfma32<T>(kfr[s % RING], qf[qb][s], sn_[qb]);
       }
       stream_ops(sc_, std::integral_constant<int, 16 + kk>{}, u_c);
+      if constexpr (kk == 15) {  // the branch condition of the phase boundary, in the shadow the stream leaves empty
+        rare_flag = chk_bal | need_mask;
+        asm volatile("" : "+s"(rare_flag));
+      }
       if constexpr ((kk & 1) && kk >= 17 - 2 * RA) vfr[(kk - (17 - 2 * RA)) / 2] = v_read(vbp, (kk - (17 - 2 * RA)) / 2);
-      extra(kk);
+      extra(kk_c);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -1165,12 +1315,11 @@ prefill_attn_w4_kernel(
   // are in sn_ ((tn, kbn) = that unit).
   // Exit: kfr[0..RA-1] hold the first k-steps of the K block at kbp_next (the unit after the next).
   auto phase_b = [&](auto u_c, const lds_char* vbp, const lds_char* kbp_next, const f32x16(&sc_)[2], f32x16(&sn_)[2],
-                     int tn, int kbn, auto extra) __attribute__((always_inline)) {
+                     int tn, int kbn, unsigned long long need_mask, auto extra) __attribute__((always_inline)) {
     constexpr int U = decltype(u_c)::value;
-    const bool need_mask = 2 * tn + kbn >= mask_lo;
-    if (__builtin_expect((chk_bal != 0) | need_mask, 0)) {  // one branch on the common path for both
+    if (__builtin_expect(rare_flag != 0, 0)) {  // one compare and one branch on the common path for both
       if (chk_bal != 0) fix_and_replay(sc_, u_c);
-      if (need_mask) {
+      if (need_mask != 0) {
         unit_mask(tn, kbn, sn_);
         if (mask_lo < u_cend && 2 * tn + kbn + 1 >= u_cend) mask_lo = u_amask;
       }
@@ -1184,14 +1333,41 @@ prefill_attn_w4_kernel(
       stream_ops(sn_, kk_c, std::integral_constant<int, 1 - U>{});
       // the next phase A's first RA K fragments, one per odd shadow up to the last one
       if constexpr ((kk & 1) && kk >= 17 - 2 * RA) kfr[(kk - (17 - 2 * RA)) / 2] = k_read(kbp_next, (kk - (17 - 2 * RA)) / 2);
-      extra(kk);
+      extra(kk_c);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+  // unit index >= mask_lo as an all-ones / zero SGPR pair, by scalar instructions (written in C the compare lands on
+  // the VALU, in front of the branch that waits for it)
+  auto unit_needs_mask = [&](int u) __attribute__((always_inline)) {
+    unsigned long long m;
+    asm volatile("s_cmp_ge_i32 %1, %2\n\ts_cselect_b64 %0, -1, 0" : "=s"(m) : "s"(u), "s"(mask_lo) : "scc");
+    return m;
+  };
   auto no_extra = [](int) {};
+  (void)no_extra;
   constexpr std::integral_constant<int, 0> U0{};
   constexpr std::integral_constant<int, 1> U1{};
 
+#if P4_DMA
+  // ---- prologue: tiles 0, 1 and 2 on their way to LDS; S(0, keys 0-31) and its bookkeeping unpipelined ----------------
+  // (An out-of-range lane of a DMA writes ZEROS to its LDS bytes - tools/dbg/probe_dma.cpp - so every byte a fragment read
+  // takes has been written by a DMA of its tile: rows past the end of a tile are zero rows, as with register staging.)
+  // waits for the wave's own DMAs are counted by hand (the instructions are inline asm); `left` = DMAs that may stay in
+  // flight.  The barrier that follows makes every wave's blocks of the awaited tile visible to all.
+  auto dma_tile = [&](int buf) __attribute__((always_inline)) {
+    const uint32_t dk = dma_dst_k(buf), dv = dma_dst_v(buf);
+    static_for<0, 4>([&](auto j_c) __attribute__((always_inline)) { dma_k(dk, j_c, std::false_type{}); });
+    static_for<0, 4>([&](auto j_c) __attribute__((always_inline)) { dma_v(dv, j_c, std::false_type{}); });
+  };
+  tile_desc(0);
+  dma_tile(0);
+  tile_desc(1);
+  dma_tile(1);
+  tile_desc(2);
+  dma_tile(2);
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tiles 0 and 1 have landed
+#else
   // ---- prologue: tiles 0 and 1 staged, tiles 2 and 3 in flight; S(0, keys 0-31) and its bookkeeping unpipelined ----
   // A tile's loads are issued two iterations before its LDS writes (two register sets): every workgroup of a
   // kv-head walks the same K/V stream at the same pace, so each fetch is a miss somewhere and all of them wait for it.
@@ -1207,6 +1383,7 @@ prefill_attn_w4_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) gload_piece(0, i);
   lds_barrier();
+#endif
   f32x16 sX[2], sY[2];
   {
     const lds_char* kbp = k_ptr(0, 0);
@@ -1230,6 +1407,78 @@ prefill_attn_w4_kernel(
 #pragma unroll
     for (int f = 0; f < RA; ++f) kfr[f] = k_read(kb1, f);
   }
+#if P4_DMA
+  // one tile = two units; cur = t % 4 = the LDS buffer of tile t.  The DMAs of tile t+3 (buffer (t+3) % 4, which tile t-1
+  // left at the last barrier) are issued in the first unit - K blocks in phase A, V blocks in phase B - and the tile ends
+  // with the counted wait that retires tile t+2 (its eight DMAs per wave were issued a tile ago) in front of the barrier.
+  auto tile_body = [&](int t, int cur, auto app_c) __attribute__((always_inline)) {
+    constexpr bool APP = decltype(app_c)::value;  // every tile loaded from here on is an appended one
+    const int nxt = (cur + 1) & 3;   // (t + 1) % 4
+    const int nxt3 = (cur + 3) & 3;  // (t + 3) % 4
+#ifdef P4_TS_SLOT
+    P4_STAMP(ts_a);
+#endif
+    // unit (t, keys 0-31): logits in sX; the next unit is (t, keys 32-63), then (t + 1, keys 0-31)
+    {
+      const lds_char* vbp = v_ptr(cur, 0);
+      const unsigned long long nm0 = unit_needs_mask(2 * t + 1);  // the unit after this one (see phase_b)
+      const uint32_t dk = dma_dst_k(nxt3), dv = dma_dst_v(nxt3);
+      phase_a(U0, k_ptr(cur, 1), vbp, sX, sY, nm0, [&](auto kk_c) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_c)::value;
+        if constexpr (kk == 0) {
+          if constexpr (APP)
+            tile_desc_app();
+          else
+            tile_desc(t + 3);
+        }
+        if constexpr ((kk & 3) == 3) dma_k(dk, std::integral_constant<int, (kk >> 2)>{}, app_c);
+      });
+      phase_b(U0, vbp, k_ptr(nxt, 0), sX, sY, t, 1, nm0, [&](auto kk_c) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_c)::value;
+        if constexpr ((kk & 3) == 3) dma_v(dv, std::integral_constant<int, (kk >> 2)>{}, app_c);
+      });
+    }
+    // unit (t, keys 32-63): logits in sY.  On the last tile S(t + 1) is computed from a stale K tile and never used.
+    {
+      const lds_char* vbp = v_ptr(cur, 1);
+      const unsigned long long nm1 = unit_needs_mask(2 * t + 2);
+      phase_a(U1, k_ptr(nxt, 0), vbp, sY, sX, nm1, [](auto) {});
+      phase_b(U1, vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, nm1, [](auto) {});
+    }
+    P4_SLOT_STAMP(64);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef P4_TS_SLOT
+    P4_STAMP(ts_e);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // s_memtime lands in its SGPR pair asynchronously: the pairs must stay reserved until the wait above, in EVERY copy
+    // of the tile body (a dead stamp's pair would otherwise be reused at once and overwritten late by the counter)
+    asm volatile("" ::"s"(ts_a), "s"(ts_k), "s"(ts_e));
+    if (t == 16 && tid == P4_TS_WAVE * 64 && bid < 8192) {
+      g_p4_slot[bid * 4 + 0] = ts_a;
+      g_p4_slot[bid * 4 + 1] = ts_k;
+      g_p4_slot[bid * 4 + 2] = ts_e;
+      g_p4_slot[bid * 4 + 3] = ntiles;
+    }
+#endif
+  };
+  int cur = 0;  // t % 4
+  PF_RT(1);
+  int t = 0;
+  // tiles whose DMA (tile t + 3) may still be a cached tile: the generic descriptor step
+  for (; t < ntiles && t + 3 < ntc; ++t) {
+    tile_body(t, cur, std::false_type{});
+    cur = (cur + 1) & 3;
+  }
+  // t + 3 >= ntc from here on: only appended tiles (or nothing) are left to load
+  for (; t < ntiles; ++t) {
+    tile_body(t, cur, std::true_type{});
+    cur = (cur + 1) & 3;
+  }
+  PF_RT(2);
+  // no DMA may land in the O staging image: the last tiles' (empty) DMAs are retired, and every wave has passed the last
+  // tile's barrier, before anything is written
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#else
   // tile 1 (set 1) to LDS; its set then receives tile 3
 #pragma unroll
   for (int i = 0; i < 8; ++i) lstore_piece(1, 1, i);
@@ -1251,11 +1500,12 @@ prefill_attn_w4_kernel(
     // unit (t, keys 0-31): logits in sX; the next unit is (t, keys 32-63), then (t + 1, keys 0-31)
     {
       const lds_char* vbp = v_ptr(cur, 0);
-      phase_a(U0, k_ptr(cur, 1), vbp, sX, sY, [&](int kk) __attribute__((always_inline)) {
+      const unsigned long long nm0 = unit_needs_mask(2 * t + 1);  // the unit after this one (see phase_b)
+      phase_a(U0, k_ptr(cur, 1), vbp, sX, sY, nm0, [&](int kk) __attribute__((always_inline)) {
         if (kk == 5) lstore_loop(SET, nxt2, 0);
         if (kk == 11) lstore_loop(SET, nxt2, 1);
       });
-      phase_b(U0, vbp, k_ptr(nxt, 0), sX, sY, t, 1, [&](int kk) __attribute__((always_inline)) {
+      phase_b(U0, vbp, k_ptr(nxt, 0), sX, sY, t, 1, nm0, [&](int kk) __attribute__((always_inline)) {
         if (kk == 5) lstore_loop(SET, nxt2, 2);
         if (kk == 11) lstore_loop(SET, nxt2, 3);
       });
@@ -1267,11 +1517,12 @@ prefill_attn_w4_kernel(
     // same register set follow in the last phase, each after the write of its piece.
     {
       const lds_char* vbp = v_ptr(cur, 1);
-      phase_a(U1, k_ptr(nxt, 0), vbp, sY, sX, [&](int kk) __attribute__((always_inline)) {
+      const unsigned long long nm1 = unit_needs_mask(2 * t + 2);
+      phase_a(U1, k_ptr(nxt, 0), vbp, sY, sX, nm1, [&](int kk) __attribute__((always_inline)) {
         if (kk == 5) lstore_loop(SET, nxt2, 4);
         if (kk == 11) lstore_loop(SET, nxt2, 5);
       });
-      phase_b(U1, vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, [&](int kk) __attribute__((always_inline)) {
+      phase_b(U1, vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, nm1, [&](int kk) __attribute__((always_inline)) {
         if (kk == 0) lstore_loop(SET, nxt2, 6);
         if (kk == 2) lstore_loop(SET, nxt2, 7);
         if constexpr (APP) {
@@ -1323,6 +1574,7 @@ prefill_attn_w4_kernel(
   if (t < ntiles) tile_body(t, cur, std::integral_constant<int, 0>{}, std::true_type{});
   PF_RT(2);
 
+#endif
 #ifdef P4_DECOUPLE_LOADS
 #pragma unroll
   for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(sink[i]));
