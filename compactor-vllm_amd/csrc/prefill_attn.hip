@@ -1291,6 +1291,7 @@ prefill_attn_w4_kernel(
       constexpr int kk = decltype(kk_c)::value;
       constexpr int s = kk >> 1, qb = kk & 1;
       P4_SLOT_STAMP(32 * decltype(u_c)::value + kk);
+      extra(kk_c);  // (the staging work of the shadow first: a DMA issued behind the shadow's LDS reads costs ~4 cycles more)
       if (qb == 0 && s + RA < KS) kfr[(s + RA) % RING] = k_read(kbp, s + RA);
       if (s == 0) {
         f32x16 z;
@@ -1306,7 +1307,6 @@ prefill_attn_w4_kernel(
         asm volatile("" : "+s"(rare_flag));
       }
       if constexpr ((kk & 1) && kk >= 17 - 2 * RA) vfr[(kk - (17 - 2 * RA)) / 2] = v_read(vbp, (kk - (17 - 2 * RA)) / 2);
-      extra(kk_c);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -1328,12 +1328,12 @@ prefill_attn_w4_kernel(
       constexpr int kk = decltype(kk_c)::value;
       constexpr int i = kk >> 1, qb = kk & 1;
       P4_SLOT_STAMP(32 * U + 16 + kk);
+      extra(kk_c);  // (the staging work of the shadow first: a DMA issued behind the shadow's LDS reads costs ~4 cycles more)
       if (qb == 0 && i + RA < 8) vfr[(i + RA) % RING] = v_read(vbp, i + RA);
       pv_mfma_w<T, P4_ACC0 + 16 * (4 * qb + (i & 3)), (kk < 8 ? P4_VPW0 + 8 * U : P4_VPW1) + 4 * qb>(vfr[i % RING]);
       stream_ops(sn_, kk_c, std::integral_constant<int, 1 - U>{});
       // the next phase A's first RA K fragments, one per odd shadow up to the last one
       if constexpr ((kk & 1) && kk >= 17 - 2 * RA) kfr[(kk - (17 - 2 * RA)) / 2] = k_read(kbp_next, (kk - (17 - 2 * RA)) / 2);
-      extra(kk_c);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
