@@ -934,10 +934,16 @@ prefill_attn_w4_kernel(
   // otherwise drain vmcnt to 0 in front of every ds_read that may alias the destination.  The waits are placed by hand
   // (dma_wait).
   auto dma16 = [&](const u32x4& rs, uint32_t voff, uint32_t dst, auto j_c) __attribute__((always_inline)) {
+#if defined(P4_NO_DMA)  // timing-only A/B builds (wrong results): what the loop's DMAs cost, and what their M0 writes cost
+    (void)rs, (void)voff, (void)dst;
+#elif defined(P4_DMA_SAMEM0)
+    asm volatile("buffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "memory");
+#else
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :
                  : "s"(dst), "v"(voff), "s"(rs), "i"(1024 * decltype(j_c)::value)
                  : "memory", "scc");
+#endif
   };
   // LDS byte address of the wave's first K / V block of buffer `buf`
   auto dma_dst_k = [&](int buf) __attribute__((always_inline)) { return lds0 + (uint32_t)(buf * P4_KTILE + wv * 4096); };
@@ -1446,7 +1452,11 @@ prefill_attn_w4_kernel(
       phase_b(U1, vbp, k_ptr(nxt, 1), sY, sX, t + 1, 0, nm1, [](auto) {});
     }
     P4_SLOT_STAMP(64);
+#ifdef P4_NO_BARRIER  // timing-only A/B build (results may be wrong): what the one barrier per tile costs
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #ifdef P4_TS_SLOT
     P4_STAMP(ts_e);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

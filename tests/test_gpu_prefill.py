@@ -202,15 +202,18 @@ def _both_structures(fn):
     return out4, out8
 
 
+@pytest.mark.parametrize("jump", [30.0, 300.0])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_prefill_both_structures_and_deferred_rescale(dev, dtype):
-    """The 4-wave kernel defers the rescale of O until a row's max has grown by more than 2^8 (P4_THR) and updates the
-    running max per 32-key unit; the 8-wave kernel rescales on any growth, per 64-key tile.  A bounded random input
-    never takes the rescale branch after the first tiles, so this input is built to take BOTH branches many times
-    (MI355X guide rule 26): logits along one direction that climb in small steps (a few units of 2^x per 32 keys:
-    deferred), jump by far more than the threshold (rescale), fall, and climb again - over a cached prefix and an
-    appended block, for query rows of different scale.  Both kernels must meet the attention tolerance against the
-    fp32 oracle; so must their difference."""
+def test_prefill_both_structures_and_deferred_rescale(dev, dtype, jump):
+    """The 4-wave kernel computes probabilities against a per-row reference point that follows the row max only when a
+    check of the packed probabilities finds one >= 2 (a logit bias + 1 above the row max of the last update; 32-key
+    units), then replays the unit; the 8-wave kernel defers its rescale until the exact row max has grown by more than
+    2^8, per 64-key tile.  A bounded random input never takes those branches after the first tiles, so this input is
+    built to take BOTH sides many times (MI355X guide rule 26): logits along one direction that climb in small steps
+    (a few units of 2^x per 32 keys: no update), jump by far more than the threshold (update + replay), fall, and climb
+    again - over a cached prefix and an appended block, for query rows of different scale.  jump = 30 overflows the fp16
+    probabilities of the unit that meets it (2^28), jump = 300 overflows fp32 itself (2^298): neither may reach O or l.
+    Both kernels must meet the attention tolerance against the fp32 oracle; so must their difference."""
     from compactor_vllm_amd.attention.sparse_varlen_kernel import causal_sparse_varlen_with_cache
 
     B, HQ, HKV, D, PS = 1, 8, 2, 128, 128
@@ -223,10 +226,10 @@ def test_prefill_both_structures_and_deferred_rescale(dev, dtype):
     scale = 1.0 / math.sqrt(D)
 
     def staircase(n, start):
-        # target logit (exp2 domain) of key j along u for a query q = qs * u: steps of +2.5 per 32 keys, a +30 jump
-        # every 400 keys, a -40 drop every 700
+        # target logit (exp2 domain) of key j along u for a query q = qs * u: steps of +2.5 per 32 keys, a +jump step
+        # every 400 keys (key 400 k + 16 of a unit: in the middle of it), a drop of 4/3 of it every 700
         j = torch.arange(n) + start
-        return 2.5 * (j // 32) + 30.0 * (j // 400) - 40.0 * (j // 700)
+        return 2.5 * (j // 32) + jump * ((j + 16) // 400) - (jump * 4 / 3) * (j // 700)
 
     qs = 8.0
     c = scale * 1.4426950408889634
