@@ -55,6 +55,9 @@ def bench_decode(args):
     splits_list = [args.splits] if args.splits else [16, 32, 64]
     bytes_alg = 2 * D * 2 * B * HKV * L + 2 * B * HQ * D * 2
     from compactor_vllm_amd import _lib
+    if args.flush:
+        junk_a = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+        junk_b = torch.empty_like(junk_a)
     for variant in [0]:
         for S in splits_list:
             dk.plan_internal_splits = lambda n_bh, bound, ks, S=S: S
@@ -64,6 +67,8 @@ def bench_decode(args):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for kc, vc in caches:
+                    if args.flush:  # stream 256 MB through the L2s between launches: the metadata lines go cold, as they
+                        junk_b.copy_(junk_a)  # do between two layers of a decode step (the GEMVs' weights in between)
                     out = dk.head_sparse_decode_attention(q, kc, vc, lens, pt, bm, HKV, PS)
             us = time_fn(g.replay, iters=50, warmup=max(3, int(40e3 / (25.0 * layers)))) / layers  # ~40 ms of warm replays: settled clocks
             print(f"decode variant={variant} B={B} L={L} splits={S:3d} layers={layers}: {us:8.2f} us/(stage1+merge)  "
@@ -165,6 +170,7 @@ if __name__ == "__main__":
     ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--flush", action="store_true", help="decode: a 128 MB device copy between launches (cold metadata, as inside a decode step)")
     ap.add_argument("--iters", type=int, default=0)      # scoring: timed calls per item (0 = default)
     ap.add_argument("--warmup", type=int, default=-1)    # scoring: warm calls per item (-1 = default)
     ap.add_argument("--with-producer", action="store_true")  # scoring: add the f-2 producer kernel
