@@ -193,3 +193,34 @@ def test_compression_params_defaults_and_snapkv_rule():
     assert (p.temperature, p.max_new_tokens) == (1.0, 256)
     with pytest.raises(ValueError):
         SamplingParams(temperature=-0.1)
+
+
+def test_register_audit_flags_compiler_use_of_asm_owned_registers(tmp_path):
+    """tools/audit_acc_regs.py is what keeps hipcc out of the registers the 4-wave prefill kernel owns through inline
+    asm (a[128:255]: output accumulators, v[222:255]: softmax state).  Synthetic assembly: clean, a compiler-emitted
+    instruction on an owned AGPR, one on an owned VGPR tuple, and scratch use - the first passes, the others fail; the same
+    names inside an ;;#ASMSTART / ;;#ASMEND pair are the kernel's own and pass."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_acc_regs", os.path.join(root, "tools", "audit_acc_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def asm(body, scratch=0):
+        name = "_ZN5cvllm22prefill_attn_w4_kernelINS_4BF16ELi4EEEvPKt"
+        return (f"{name}:\n{body}\n.Lfunc_end0:\n"
+                f".amdhsa_kernel {name}\n\t.amdhsa_private_segment_fixed_size {scratch}\n.end_amdhsa_kernel\n")
+
+    own = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 a[128:143], v[4:7], v[232:235], a[128:143]\n\tv_add_f32 v224, v224, v228\n\t;;#ASMEND\n"
+    cases = {
+        "clean": (asm(own + "\tv_mfma_f32_32x32x16_bf16 v[50:65], v[80:83], v[100:103], v[50:65]\n\tv_add_u32_e32 v221, v1, v2\n"), 0),
+        "agpr": (asm(own + "\tv_accvgpr_read_b32 v3, a130\n"), 1),
+        "vgpr": (asm(own + "\tds_read_b128 v[220:223], v9\n"), 1),
+        "scratch": (asm(own, scratch=16), 1),
+    }
+    for key, (text, want) in cases.items():
+        p = tmp_path / f"{key}.s"
+        p.write_text(text)
+        assert len(mod.audit(str(p))) == want, key
