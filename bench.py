@@ -246,9 +246,9 @@ def roofline_prefill_attn(model, ctx, rounds=3):
     return {"bound": "mfma", "kernel": kern, "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "avg_launch_us": round(sec * 1e6, 1), "algorithmic_flops_per_launch": flops,
-            "note": "peak = the guide's dense bf16 figure at 2.4 GHz; profiles/r02_prefill_workgroup_stamps.txt measures "
-                    "2.03 GHz shader clock inside this kernel (s_memtime / s_memrealtime), i.e. 2.13 PFLOP/s at the "
-                    "delivered clock"}
+            "note": "peak = the guide's dense bf16 figure at 2.4 GHz; profiles/r03_prefill_workgroup_stamps.txt measures "
+                    "1.83 GHz shader clock inside this kernel (s_memtime / s_memrealtime; the chip is power-limited here), "
+                    "i.e. 1.90 PFLOP/s at the delivered clock"}
 
 
 @torch.inference_mode()
