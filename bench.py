@@ -491,6 +491,14 @@ def main():
     import bench_shell as bs
     from compactor_vllm_amd import (LLM, BatchCompressionParams, CompressionMethod, LLMConfig, SamplingParams,
                                     SequenceCompressionParams)
+    shared_device = world > ndev
+    if shared_device:
+        # rehearsal only: ranks that share a GPU time-slice its CUs, so a launch's workgroups are not co-resident and the
+        # in-launch split merge of decode attention would time out (and say so: cvllm_decode_merge_status) - use the
+        # two-kernel merge, which has no such requirement
+        import compactor_vllm_amd.attention.sparse_decode_kernel as _dk
+
+        _dk.set_merge_mode("two-kernel")
 
     shape, ctx, new, method_name, ratio = WORKLOADS[args.workload]
     ctx = args.ctx or ctx
@@ -585,7 +593,8 @@ def main():
                         f"(LLM.generate: scheduler, paged KV cache, continuous batching)",
             "ctx": ctx, "new_tokens": new, "method": method_name, "ratio": ratio, "sequences_per_gpu": nseq,
             "parallelism": f"replicas x{world} (a global list of {n_req} requests sharded by bench_dist.partition_lpt, "
-                           f"no collectives)",
+                           f"no collectives)"
+                           + (f"; REHEARSAL: {world} ranks share {ndev} GPU(s) (gloo), two-kernel decode merge" if shared_device else ""),
         },
     }
     if rank == 0 and args.no_roofline:
