@@ -23,6 +23,7 @@ decode step while `position < prompt_len + max_new_tokens` (`:408-411`).
 from __future__ import annotations
 
 import logging
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -81,6 +82,8 @@ class ModelRunner:
         self.prefix_cache = PrefixCache()
         self._batch_params: Optional[BatchCompressionParams] = None
         self.kv_manager.goes_alone = self._has_prefix_hit
+        if self.on_gpu:
+            self._probe_in_launch_merge()
 
     # ------------------------------------------------------------------------------------------------ prefill
     @torch.inference_mode()
@@ -237,6 +240,32 @@ class ModelRunner:
         if select_status() != 0:
             raise RuntimeError("KV selection failed: a slice of the ordered write timed out waiting for the slices "
                                "before it (cvllm_select_status); the retained sets of this prefill are incomplete")
+
+    def _probe_in_launch_merge(self) -> None:
+        """Once, at start-up: ONE synthetic decode-attention launch that fills the chip the way the engine's launches do
+        (256 workgroups, in-launch split merge), then the status word.  A device whose CUs this process does not have to
+        itself at that moment - a CU mask, another process on the same GPU - fails HERE, where nothing is lost: the
+        process then uses the two-kernel merge from the first token on.  (Contention that begins later is still caught
+        by `_check_decode_health`.)"""
+        from ..attention import sparse_decode_kernel as dk
+
+        if os.environ.get("CVLLM_MERGE_PROBE", "1") == "0":  # tests of the later check (`_check_decode_health`) skip it
+            return
+        HKV, D, PS, P = self.num_kv_heads, int(self.kv_manager.head_dim), 128, 8
+        hq = int(self.config.hf_config.num_attention_heads)
+        dt, dev = self.kv_manager.model_dtype, self.device
+        kc = torch.zeros(HKV * P * PS, D, dtype=dt, device=dev)
+        q = torch.zeros(1, hq, D, dtype=dt, device=dev)
+        pt = torch.arange(HKV * P, dtype=torch.int32, device=dev).view(1, HKV, P)
+        lens = torch.full((1, HKV), P * PS, dtype=torch.int32, device=dev)
+        bm = torch.zeros(1, dtype=torch.int32, device=dev)
+        dk.head_sparse_decode_attention(q, kc, kc, lens, pt, bm, HKV, PS, key_split=max(1, 256 // HKV))
+        if dk.merge_status(dev) != 0:
+            dk.set_merge_mode("two-kernel")
+            import warnings
+
+            warnings.warn("decode attention: the in-launch split merge timed out in the start-up probe (the GPU's CUs are "
+                          "not this process's alone); using the two-kernel merge")
 
     def _check_decode_health(self) -> None:
         """After every decode loop (the loop has just copied its tokens to the host, so the device is idle): the

@@ -247,9 +247,56 @@ def test_engine_reports_in_launch_merge_timeout_and_falls_back(dev):
     lib = os.path.join(root, "tools", "dbg", "libcvllm_dec_withhold.so")
     if not os.path.exists(lib):
         pytest.fail("tools/dbg/libcvllm_dec_withhold.so missing: run __graft_entry__.build()")
-    env = dict(os.environ, CVLLM_LIB_PATH=lib)
+    env = dict(os.environ, CVLLM_LIB_PATH=lib, CVLLM_MERGE_PROBE="0")  # (the start-up probe would catch it first: below)
     env.pop("CVLLM_DECODE_MERGE", None)
     r = subprocess.run([sys.executable, "-c", _FALLBACK_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = r.stdout.strip().splitlines()
     assert "RAISED" in lines and "FALLBACK_OK" in lines, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_PROBE_CHILD = r'''
+import os, sys, warnings, torch
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "compactor-vllm_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+from tiny_model import TinyConfig, TinyModel
+from compactor_vllm_amd import LLM, LLMConfig, SamplingParams, BatchCompressionParams, CompressionMethod
+from compactor_vllm_amd.attention import sparse_decode_kernel as dk
+dev = torch.device("cuda:0")
+cfg = TinyConfig()
+conf = LLMConfig(model="tiny", max_num_seqs=2, max_model_len=4096, hf_config=cfg, eos=-1, kvcache_page_size=128,
+                 enforce_eager=False, show_progress_bar=False)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    eng = LLM(conf, TinyModel(cfg, dev), device=dev, num_pages=80, max_batched_tokens=4096)
+print("WARNED" if any("start-up probe" in str(x.message) for x in w) else "NO_WARNING")
+prev = dk.set_merge_mode("two-kernel")
+print("SWITCHED" if prev == "two-kernel" else "MODE " + prev)
+g = torch.Generator().manual_seed(3)
+prompt = torch.randint(0, 512, (3000,), generator=g).tolist()
+out = eng.generate([prompt], SamplingParams(temperature=0.0, max_new_tokens=4),
+                   BatchCompressionParams(compression_method=CompressionMethod.NONE))
+print("GENERATED" if len(out) == 1 and dk.merge_status(dev) == 0 else "BAD")
+'''
+
+
+def test_engine_startup_probe_moves_to_two_kernel_merge(dev):
+    """ModelRunner's start-up probe (one synthetic chip-filling decode launch + the status word): with the debug build in
+    which split 1 withholds its numerators - the stand-in for a GPU whose CUs are not the process's alone - the engine
+    warns, runs on the two-kernel merge from the first token on, and generate() works."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "dbg", "libcvllm_dec_withhold.so")
+    if not os.path.exists(lib):
+        pytest.fail("tools/dbg/libcvllm_dec_withhold.so missing: run __graft_entry__.build()")
+    env = dict(os.environ, CVLLM_LIB_PATH=lib)
+    env.pop("CVLLM_DECODE_MERGE", None)
+    env.pop("CVLLM_MERGE_PROBE", None)
+    r = subprocess.run([sys.executable, "-c", _PROBE_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert "WARNED" in lines and "SWITCHED" in lines and "GENERATED" in lines, r.stdout[-2000:] + r.stderr[-2000:]
