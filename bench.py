@@ -86,7 +86,7 @@ def prefill_only(llm, prompts, bcp, ratio):
 
 
 @torch.inference_mode()  # like the engine: its graphs register RNG state as inference tensors
-def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
+def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True, live_pmc=False):
     """Achieved HBM GB/s of decode attention AS THE REFERENCE DEFINES IT (a2 = stage 1 + split merge,
     cv/attention/sparse_decode_kernel.py:246-435) on the REAL post-prefill cache of every layer (distinct memory per
     layer, 2.2 GB per pass => cold L2 / Infinity Cache, like inside a decode step).
@@ -158,7 +158,14 @@ def roofline_decode_attn(model, state, workload, rounds=5, use_graph=True):
                                        None)
     fits = B * cfg.kv_heads * n_splits <= dk._cus(dev.index)
     one_kernel = n_splits == 1 or (fits and not os.environ.get("CVLLM_DECODE_MERGE", "").startswith(("t", "2")))
-    traffic, traffic_src = pmc_traffic(workload, int(avg_bytes))
+    traffic, traffic_src = None, "live counter pass not requested"
+    if live_pmc and cfg.kv_heads == 8 and cfg.head_dim == 128 and cfg.heads == 32:
+        L_rows = int(round((avg_bytes - 2 * B * 32 * 128 * 2) / (2 * 128 * 2 * B * 8)))
+        traffic, traffic_src = pmc_traffic_live(B, L_rows, n_splits, int(avg_bytes))
+    if traffic is None:  # fall back to the committed record of the collection run (and say which of the two it is)
+        live_why = traffic_src
+        traffic, traffic_src = pmc_traffic(workload, int(avg_bytes))
+        traffic_src = f"{traffic_src}  [no live figure: {live_why}]"
     out = {"bound": "hbm",
            "kernel": "decode_fused_kernel (K/V streaming + in-launch split merge: the whole of reference a2)"
                      if one_kernel else "decode_fused_kernel + decode_stage2_kernel (K/V streaming, then the split merge: "
@@ -378,6 +385,56 @@ def pmc_traffic(workload, alg_bytes):
         return None, f"unreadable: {type(exc).__name__}"
 
 
+def pmc_traffic_live(B, L, splits, alg_bytes, timeout_s=240):
+    """(HBM bytes per launch, source) measured NOW, on this box: two child runs of `rocprofv3 --pmc <counter>
+    --kernel-include-regex decode_fused` (separate passes for FETCH_SIZE and WRITE_SIZE, collection limited to the roofline
+    kernel) over tools/microbench.py's decode leg - the same kernel through the same C-ABI call at this run's per-layer shape
+    (B sequences, L rows per kv-head, `splits` key splits).  hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 rule
+    of MI355X_MICROARCH.md).  A process cannot read these counters about itself, hence the children; they run while this
+    process idles.  Returns (None, reason) if the profiler is missing, fails, or the shapes' algorithmic bytes disagree."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this process is itself being profiled"
+    micro_alg = 2 * 128 * 2 * B * 8 * L + 2 * B * 32 * 128 * 2
+    if abs(micro_alg - alg_bytes) > 0.02 * alg_bytes:
+        return None, "microbench shape does not reproduce this run's algorithmic bytes"
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out_dir = os.path.join(td, ctr)
+                cmd = [exe, "--pmc", ctr, "--kernel-include-regex", "decode_fused", "--kernel-trace", "--output-format",
+                       "csv", "-d", out_dir, "--", sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "decode",
+                       "--B", str(B), "--L", str(L), "--splits", str(splits)]
+                r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                                   timeout=timeout_s)
+                if r.returncode != 0:
+                    return None, f"rocprofv3 --pmc {ctr} over tools/microbench.py: rc {r.returncode}"
+                vals = []
+                for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                    with open(f, newline="") as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] == ctr and "decode_fused" in row["Kernel_Name"]:
+                                vals.append(float(row["Counter_Value"]))
+                if not vals:
+                    return None, f"rocprofv3 --pmc {ctr}: no rows for decode_fused_kernel"
+                got[ctr] = (sum(vals) / len(vals), len(vals))
+    except Exception as exc:  # noqa: BLE001
+        return None, f"live counter pass failed: {type(exc).__name__}"
+    hbm = int((2 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024)
+    return hbm, (f"live, this run: rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-include-regex decode_fused --kernel-trace -- "
+                 f"python3 tools/microbench.py decode --B {B} --L {L} --splits {splits} (two child passes, "
+                 f"{got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024)")
+
+
 def cpu_baseline(budget_s=25.0):
     """The hot path on the host cores with the CPU oracle (kind 'port'), on BASELINE.json configs[0] (C1: HQ 32 / HKV 8 /
     D 128 / page 128, ONE 4 096-token sequence, dense attention, fp16 like the reference's test shapes): one layer's
@@ -458,6 +515,9 @@ def main():
     ap.add_argument("--serial-store", action="store_true",
                     help="A/B: run the scoring / selection / compaction chain on the main stream instead of the store stream")
     ap.add_argument("--no-roofline", action="store_true", help="A/B runs: only the tokens/s line")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="roofline.traffic from the committed profiles/*_bench_pmc.json instead of two live rocprofv3 --pmc "
+                         "child passes (~40 s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -601,7 +661,8 @@ def main():
         print(json.dumps(result), flush=True)
     elif rank == 0:
         state = prefill_only(llm, prompts, bcp, ratio)  # a prefill whose cache stays allocated: the real cache
-        result["roofline"] = roofline_decode_attn(model, state, args.workload, use_graph=not args.no_graph)
+        result["roofline"] = roofline_decode_attn(model, state, args.workload, use_graph=not args.no_graph,
+                                                  live_pmc=(world == 1 and not args.no_live_pmc))
         copy_bw = copy_bandwidth_gbs(dev)
         result["roofline"]["copy_bw"] = round(copy_bw, 1)  # measured device copy rate: the practical HBM roof
         result["roofline"]["frac_of_copy_bw"] = round(result["roofline"]["achieved"] / copy_bw, 4)

@@ -7,7 +7,7 @@ R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 mkdir -p "$O"
-B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq"
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-multi-seq --no-live-pmc"
 # 1. kernel trace + the tool's own stats of the bench command (C3 through the engine); the decode kernels' mean durations
 #    of THIS trace become profiles/<R>_bench_decode_rocprof.json, which bench.py prints beside its event-timed figure
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- $B > "$O/bench_under_rocprof.log" 2>&1
