@@ -44,22 +44,13 @@ __device__ __forceinline__ f32x16 mfma32<BF16>(s16x8 a, s16x8 b, f32x16 c) {
 
 // The 4-wave kernel's output accumulators O^T (2 query blocks x 4 head-dim blocks x 16 registers) live in the ACC
 // registers a[128:255], owned by inline asm (the structure the CDNA guide names for this kernel shape).  Why: the kernel
-// is built with -amdgpu-mfma-vgpr-form so that hipcc's own MFMAs - the QK^T chains, whose results the VALU reads and
-// whose accumulator seed is an arch-VGPR block (negm) - take and deliver arch VGPRs; an MFMA's C and D share one
-// register-file bit, so hipcc would keep the 128 output accumulators in arch VGPRs as well: half of the file, and the
-// seed blocks no longer fit.  Here the PV MFMAs name their accumulator registers literally; the compiler allocates ITS
-// AGPRs from a0 upwards and must stay below a128 (build.py audits the code object: no compiler-emitted instruction may
-// touch a128+).  hipcc pads no hazards around an asm statement: the two places that access these registers with
+// is built with -amdgpu-mfma-vgpr-form so that hipcc's own MFMAs - the QK^T chains, whose results the VALU reads - take
+// and deliver arch VGPRs; an MFMA's C and D share one register-file bit, so hipcc would keep the 128 output accumulators
+// in arch VGPRs as well: half of the file.  Here the PV MFMAs (pv_mfma_w) name their accumulator registers literally; the
+// compiler allocates ITS AGPRs from a0 upwards and must stay below a128 (build.py audits the code object: no
+// compiler-emitted instruction may touch a128+).  hipcc pads no hazards around an asm statement: the two places that access these registers with
 // v_accvgpr_* (rare rescale, epilogue) wait out the MFMA pipeline themselves (acc_settle) and pad their writes.
 constexpr int P4_ACC0 = 128;
-template <typename T, int X>
-__device__ __forceinline__ void pv_mfma(s16x8 a, s16x8 b) {
-  static_assert(X >= P4_ACC0 && X + 15 < 256 && (X % 16) == 0, "accumulator block");
-  if constexpr (std::is_same<T, BF16>::value)
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(X), "i"(X + 15));
-  else
-    asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(X), "i"(X + 15));
-}
 template <int R>
 __device__ __forceinline__ float acc_read() {
   float t;
@@ -611,16 +602,18 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(
 // per flop), there is no co-resident wave, and the wave's own softmax VALU work is hand-placed into the 32-cycle
 // shadows of its own MFMAs (see the loop).  What bounds it: with one wave per SIMD EVERY instruction - VALU, scalar,
 // LDS, wait - takes an issue slot (>= 4 cycles) from the same in-order stream; a 64-key tile is 64 MFMAs (2048
-// cycles of matrix pipe) and ~570 instructions (~2700 issue cycles), measured 4100 cycles per tile.
+// cycles of matrix pipe) and 480 instructions; measured 2 650 cycles per tile (round 2: 4 100; the round's steps and what
+// each bought: profiles/r03_prefill_slot_timeline.txt).
 //   * workgroup = 4 waves = the same 256 rows ((256/G) tokens x G heads of one kv-head) as above, same grid order;
-//   * registers: O 128, Q fragments 64, two 32-key logit blocks 64, P 16, staging 2 x 32, fragment rings 32 (~390);
-//   * K/V tiles come in by buffer loads (tile base and valid bytes in the resource descriptor, lane-constant VGPR
-//     offsets: no per-load address arithmetic, rows past the end of the tile read as zero), issued two tiles before
-//     their LDS writes, three LDS buffers each for K and V;
-//   * same LDS images and fragment addressing as the 8-wave kernel; the softmax differs in two documented ways: the
-//     running max is updated per 32-key unit (not per 64-key tile) and follows the row max only after it has grown
-//     by more than PF_THR (deferred rescale).  Both kernels meet the attention tolerance of the parity tests
-//     (tests/test_gpu_prefill.py runs every case on both).
+//   * registers: O in a[128:255] and the softmax state the rare path rewrites in v[222:255], both owned by inline asm
+//     (see above); Q fragments 64, two 32-key logit blocks 64, fragment rings 32, DMA source offsets 16;
+//   * K/V tiles come in by LDS-DMA (buffer_load_dwordx4 ... lds: tile base and valid bytes in the resource descriptor,
+//     lane-constant source offsets, rows past the end of the tile arrive as zeros) into read-order LDS images, four
+//     buffers each for K and V, issued three tiles ahead (-DP4_DMA=0: register staging into padded images, three buffers);
+//   * the softmax differs from the 8-wave kernel's: probabilities are taken against a per-row reference point that is
+//     moved only when a check of the packed probabilities finds one >= 2 ("optimistic probabilities", in the kernel),
+//     per 32-key unit.  Both kernels meet the attention tolerance of the parity tests (tests/test_gpu_prefill.py runs
+//     every case on both).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
@@ -818,7 +811,7 @@ prefill_attn_w4_kernel(
   const int ntiles = ntc + nta;
 
   // ---- accumulators and LDS addressing ------------------------------------------------------------------------------
-  acc_zero_all();  // O^T accumulators a[128:255] (see pv_mfma): block (qb, db) = a[128 + 16 (4 qb + db) .. + 15]
+  acc_zero_all();  // O^T accumulators a[128:255] (see pv_mfma_w): block (qb, db) = a[128 + 16 (4 qb + db) .. + 15]
   // Optimistic probabilities.  A probability is exp2(s c - m_ref) with m_ref the row's REFERENCE POINT (identical in
   // lanes l and l^32): the row max as of the last update plus P4_BIAS.  Everything accumulated (O, l) and every pending
   // packed word is relative to m_ref; the row max of a unit is NOT computed on the common path.  Instead the packed
@@ -1085,17 +1078,14 @@ prefill_attn_w4_kernel(
   // The loop works in UNITS of 32 keys (half a staged tile).  For unit u (logits S(u), 16 registers per query block):
   //   phase A: 16 MFMAs  S(u+1) = K[unit u+1] Q^T      (every K fragment feeds both query blocks)
   //   phase B: 16 MFMAs  O^T   += V[unit u]^T P(u)^T   (every V fragment feeds both query blocks)
-  // and the VALU / LDS / memory work is HAND-PLACED into the 32 MFMA shadows of the unit (a slot = one MFMA + its
+  // and the VALU / LDS / memory work is HAND-PLACED into the 32 MFMA shadows of the unit (a shadow = one MFMA + its
   // fillers, closed by sched_barrier(0) so that hipcc keeps the placement; left to itself it forms one VALU lump per
-  // phase, which a single wave per SIMD cannot hide): exp2 / pack / row-sum items of P(u) over phase A and the first
-  // half of phase B (P of keys 16-31 is first needed by the 9th PV MFMA), the row max of S(u+1) and the running-max
-  // bookkeeping over the second half of phase B, the LDS writes of tile t+2 over phase A and the buffer loads of tile
-  // t+3 over phase B of the tile's second unit; fragment reads run two fragments ahead of their MFMAs (rings of 3).
-  // Budget per MFMA: 32 cycles of matrix pipe, 8 of them holding the vector issue port; one item = 2 fma + 2 exp +
-  // 2 add + 1 cvt_pk = 36 issue cycles.  Only two logit blocks (64 registers) are live: with Q (64) and the staging
-  // registers (32) the arch VGPRs hold everything the VALU touches (this file is built with -amdgpu-mfma-vgpr-form:
-  // MFMA results in arch VGPRs, no v_accvgpr_read in front of the softmax) and nothing spills.  K and V are
-  // triple-buffered: S(t+1) of a unit is computed in the same iteration that writes tile t+2.
+  // phase, which a single wave per SIMD cannot hide): the softmax stream of unit u+1 over phase B of unit u and phase A
+  // of unit u+1 (P4Stream), the unit's check between its phases, the DMAs of tile t+3 over the first unit of tile t;
+  // fragment reads run P4_RA fragments ahead of their MFMAs.  Budget per MFMA: 32 cycles of matrix pipe, 8 of them
+  // holding the vector issue port.  Only two logit blocks (64 registers) are live (this file is built with
+  // -amdgpu-mfma-vgpr-form: the QK^T results land in arch VGPRs, no v_accvgpr_read in front of the softmax) and nothing
+  // spills.
 #if P4_DMA
   constexpr int K_STEP = 1024, K_UNIT = 8192, V_FRAG = 1024, V_HI = 512, V_UNIT = 8192;
 #else
