@@ -86,6 +86,11 @@ def bench_prefill(args):
         q = torch.randn(N, HQ, D, device=dev, dtype=dtype)
         k = torch.randn(N, HKV, D, device=dev, dtype=dtype)
         v = torch.randn(N, HKV, D, device=dev, dtype=dtype)
+        if args.fused_v:  # the engine's layout: V is a strided view of the fused projection output [N, (HQ + 2 HKV) D]
+            qkv = torch.randn(N, (HQ + 2 * HKV) * D, device=dev, dtype=dtype)
+            v = qkv[:, (HQ + HKV) * D:].view(N, HKV, D)
+            if args.fused_v > 1:
+                k = qkv[:, HQ * D:(HQ + HKV) * D].view(N, HKV, D)
         kc = torch.zeros(PS, D, device=dev, dtype=dtype)
         lens = torch.zeros(B, HKV, dtype=torch.int32, device=dev)
         pt = torch.zeros(B + 1, HKV, 1, dtype=torch.int32, device=dev)
@@ -170,6 +175,7 @@ if __name__ == "__main__":
     ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--fused-v", type=int, default=0, help="prefill: 1 = V (2 = K and V) as strided views of a fused qkv buffer")
     ap.add_argument("--flush", action="store_true", help="decode: a 128 MB device copy between launches (cold metadata, as inside a decode step)")
     ap.add_argument("--iters", type=int, default=0)      # scoring: timed calls per item (0 = default)
     ap.add_argument("--warmup", type=int, default=-1)    # scoring: warm calls per item (-1 = default)
