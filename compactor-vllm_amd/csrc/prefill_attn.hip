@@ -931,11 +931,20 @@ prefill_attn_w4_kernel(
     (void)rs, (void)voff, (void)dst;
 #elif defined(P4_DMA_SAMEM0)
     asm volatile("buffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "memory");
+#elif defined(P4_DMA_SPLIT)  // A/B: M0 written one shadow ahead of the DMA (dma_m0 below), no s_nop
+    asm volatile("buffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(voff), "s"(rs) : "memory");
 #else
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :
                  : "s"(dst), "v"(voff), "s"(rs), "i"(1024 * decltype(j_c)::value)
                  : "memory", "scc");
+#endif
+  };
+  auto dma_m0 = [&](uint32_t dst, auto j_c) __attribute__((always_inline)) {
+#ifdef P4_DMA_SPLIT
+    asm volatile("s_add_u32 m0, %0, %1" : : "s"(dst), "i"(1024 * decltype(j_c)::value) : "memory", "scc");
+#else
+    (void)dst;
 #endif
   };
   // LDS byte address of the wave's first K / V block of buffer `buf`
@@ -1209,8 +1218,9 @@ prefill_attn_w4_kernel(
   // Exact row max of the unit (this lane's 16 keys, then the partner lane l ^ 32), and for every row that has climbed:
   // reference point = row max + P4_BIAS, O and l scaled once by 2^(old - new).  Rows that have not climbed keep
   // everything.  The caller replays the unit's stream afterwards.  A fully masked row has row max -inf: never taken.
-  auto row_fix = [&](const f32x16(&sc_)[2]) __attribute__((always_inline)) {
-    acc_settle();
+  auto row_fix = [&](const f32x16(&sc_)[2], auto first_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value;  // the sequence's first unit: O and l are still zero, nothing to scale
+    if constexpr (!FIRST) acc_settle();
     static_for<0, 2>([&](auto qb_c) __attribute__((always_inline)) {
       constexpr int qb = decltype(qb_c)::value;
       const f32x16& a = sc_[qb];
@@ -1229,10 +1239,11 @@ prefill_attn_w4_kernel(
       const float alpha = take ? __builtin_amdgcn_exp2f(nm_new - nm_old) : 1.f;  // 2^(old point - new point)
       asm volatile("v_mov_b32 v%c0, %1\n\tv_mul_f32 v%c2, v%c2, %3\n\tv_mul_f32 v%c4, v%c4, %3" ::"i"(P4_VNM + qb),
                    "v"(nm_new), "i"(P4_VL + qb), "v"(alpha), "i"(P4_VL2 + qb));
-      static_for<64 * qb, 64 * qb + 64>([&](auto r_c) __attribute__((always_inline)) {
-        constexpr int R = P4_ACC0 + decltype(r_c)::value;
-        acc_write<R>(acc_read<R>() * alpha);
-      });
+      if constexpr (!FIRST)
+        static_for<64 * qb, 64 * qb + 64>([&](auto r_c) __attribute__((always_inline)) {
+          constexpr int R = P4_ACC0 + decltype(r_c)::value;
+          acc_write<R>(acc_read<R>() * alpha);
+        });
     });
     asm volatile("s_nop 3" ::: "memory");  // v_accvgpr_write -> MFMA reads the register as its accumulator
   };
@@ -1274,7 +1285,7 @@ prefill_attn_w4_kernel(
   // (rare) the check fired: new reference points, then the unit's whole stream once more from its logits (without the
   // four FOLD ops, which belong to the previous unit's sums, and without the check)
   auto fix_and_replay = [&](const f32x16(&sc_)[2], auto par_c) __attribute__((always_inline)) {
-    row_fix(sc_);
+    row_fix(sc_, std::false_type{});
     static_for<4, P4_NOPS>([&](auto g_c) __attribute__((always_inline)) { micro(sc_, g_c, par_c, std::true_type{}); });
     asm volatile("s_nop 1" ::: "memory");  // VALU-written packed words -> (asm) MFMA operand
   };
@@ -1397,7 +1408,7 @@ prefill_attn_w4_kernel(
     }
     // the first unit sets the reference points (O and l are still zero: nothing else moves; every query sees key 0 of
     // its sequence, so every row takes), then runs the first half of its stream outside any MFMA shadow
-    row_fix(sX);
+    row_fix(sX, std::true_type{});
     static_for<0, 16>([&](auto sl_c) __attribute__((always_inline)) { stream_ops(sX, sl_c, std::integral_constant<int, 0>{}); });
     const lds_char* kb1 = k_ptr(0, 1);
 #pragma unroll
@@ -1427,10 +1438,12 @@ prefill_attn_w4_kernel(
           else
             tile_desc(t + 3);
         }
+        if constexpr ((kk & 3) == 2) dma_m0(dk, std::integral_constant<int, (kk >> 2)>{});
         if constexpr ((kk & 3) == 3) dma_k(dk, std::integral_constant<int, (kk >> 2)>{}, app_c);
       });
       phase_b(U0, vbp, k_ptr(nxt, 0), sX, sY, t, 1, nm0, [&](auto kk_c) __attribute__((always_inline)) {
         constexpr int kk = decltype(kk_c)::value;
+        if constexpr ((kk & 3) == 2) dma_m0(dv, std::integral_constant<int, (kk >> 2)>{});
         if constexpr ((kk & 3) == 3) dma_v(dv, std::integral_constant<int, (kk >> 2)>{}, app_c);
       });
     }
